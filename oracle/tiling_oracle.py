@@ -1,0 +1,55 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY.  Never imported by the product package.
+
+Restatement of the reference's inference tile bookkeeping (/root/reference/inference.py:65-127)
+in plain Python/numpy loops.  Integer work: the product must match it bit for bit.
+
+  drop the DC row                      inference.py:68
+  num_segments = T // seg_len + 1      inference.py:75
+  segment i = columns [i*L, i*L+L)     inference.py:80-84
+  skip empty segments (T % L == 0)     inference.py:88
+  right zero-pad short segments to L   inference.py:90-92
+  mask (or 1-mask) times mixture       inference.py:100-107
+  crop the padding off again           inference.py:113-114
+  concatenate along time               inference.py:120
+  put a zero float32 row back on top   inference.py:123
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def segment_plan(n_frames: int, seg_len: int = 128):
+    """[(start, end, pad)] for every non-empty segment, in order."""
+    plan = []
+    num_segments = n_frames // seg_len + 1
+    for i in range(num_segments):
+        start = i * seg_len
+        end = min(start + seg_len, n_frames)
+        cur = end - start
+        if cur <= 0:
+            continue
+        plan.append((start, end, seg_len - cur))
+    return plan
+
+
+def separate(mix_spec: np.ndarray, mask_fn, seg_len: int = 128, vocal_solo: bool = True) -> np.ndarray:
+    """(513, T) float32 mixture magnitude -> (513, T) float32 separated magnitude.
+    `mask_fn(tile)` maps a (1, 1, 512, seg_len) float32 array to the soft mask of the same shape."""
+    crop = mix_spec[1:, :]
+    pieces = []
+    for start, end, pad in segment_plan(crop.shape[1], seg_len):
+        seg = crop[:, start:end]
+        if pad:
+            seg = np.concatenate([seg, np.zeros((seg.shape[0], pad), seg.dtype)], axis=1)
+        tile = np.ascontiguousarray(seg[None, None]).astype(np.float32)
+        msk = np.asarray(mask_fn(tile), dtype=np.float32)
+        if not vocal_solo:
+            msk = np.float32(1.0) - msk
+        pred = (tile * msk)[0, 0]
+        if pad:
+            pred = pred[:, : end - start]
+        pieces.append(pred)
+    if not pieces:
+        return None
+    full = np.concatenate(pieces, axis=1)
+    return np.concatenate([np.zeros((1, full.shape[1]), np.float32), full], axis=0)
