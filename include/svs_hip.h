@@ -1,0 +1,215 @@
+/* libsvs_hip.so -- C ABI of the MI355X (gfx950) singing-voice-separation hot path.
+ *
+ * The reference (zouyuoz/SVS-UNet-PyTorch, cited below as <file>:<line>) has no FFI: its hot path
+ * is a chain of torch / librosa library calls made from Python.  Each entry point here replaces one
+ * of those calls (or a run of them) and is what a maintainer would bind with ctypes -- see
+ * INTEGRATION.md for the stub.  Conventions:
+ *   - every pointer is a DEVICE pointer owned by the caller (torch); the library never allocates
+ *     caller-visible memory, never synchronises the stream and holds no mutable global state;
+ *   - scratch space is passed in (void* ws, size_t ws_bytes); the matching *_workspace_bytes query
+ *     says how much is needed; 16-byte alignment is required of every tensor pointer;
+ *   - activations are fp32 NHWC "views": pointer to channel 0 of pixel 0 plus `ld`, the distance in
+ *     floats between consecutive pixels (so a channel slice of a wider buffer -- the decoder's
+ *     skip-concat halves, model.py:186-198 -- is addressed without a copy).  With one channel NHWC
+ *     and the reference's NCHW coincide, so the network input/output are the reference's tensors;
+ *   - return value: 0 = OK, <0 = invalid argument / workspace too small, >0 = hipError_t;
+ *     svs_last_error_string() returns a thread-local description of the last failure;
+ *   - re-entrant across threads and streams (torch's autograd engine calls from its own thread).
+ */
+#ifndef SVS_HIP_H
+#define SVS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+/* identical to the typedef in <hip/hip_runtime_api.h>; repeating it keeps this header free of HIP includes */
+typedef struct ihipStream_t* hipStream_t;
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVS_OK 0
+#define SVS_ERR_INVALID (-1)
+#define SVS_ERR_WORKSPACE (-2)
+#define SVS_ABI_VERSION 1
+
+int svs_version(void);
+const char* svs_last_error_string(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Synthetic data (bench / tests): the counter-based generator of svs_unet_pytorch_amd/synth.py.
+ * out[i] = uniform(seed, offset + i) * scale + shift.                       (SURVEY.md 8d inputs) */
+int svs_fill_uniform(float* out, int64_t n, uint32_t seed, uint64_t offset, float scale, float shift,
+                     hipStream_t stream);
+/* mix = u(seed 0), voc = mix * u(seed 1); counter = flat offset + 2^32 * (first_tile + b).
+ * Stands in for SpectrogramDataset.__getitem__ (train.py:86-143) in every synthetic config. */
+int svs_fill_tiles(float* mix, float* voc, int B, int H, int W, int64_t first_tile, hipStream_t stream);
+/* Dropout2d(0.5) keep-masks (model.py:83,89,95,101,107): out[b*C+c] in {0, 2}. */
+int svs_dropout_mask(float* out, int B, int C, int layer, uint32_t seed, int step, int rank, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Weight layouts.  Checkpoints keep torch's layouts (Conv2d (N,C,5,5), model.py:48; ConvTranspose2d
+ * (C,N,5,5), model.py:79); the MFMA kernels read K-contiguous packings made by these two.
+ *   gather packing  wp[n][kh][kw][c]                       = w[n][c][kh][kw]
+ *   parity packing  wp[p][n][th][tw][c], p = 2*ph+pw       = w[c][n][ph+2*th][pw+2*tw]
+ *                   (the four output-parity sub-convolutions of a stride-2 transposed conv:
+ *                    9/6/6/4 taps; block p starts at {0,9,15,21}*N*C floats) */
+int svs_pack_weight_gather(const float* w, float* wp, int N, int C, hipStream_t stream);
+int svs_pack_weight_parity(const float* w, float* wp, int C, int N, hipStream_t stream);
+
+/* Eval-mode BatchNorm folded into the producing conv's epilogue (model.py:49,81 in .eval()):
+ * scale = gamma / sqrt(running_var + eps), shift = beta + (conv_bias - running_mean) * scale. */
+int svs_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                const float* conv_bias, float eps, float* scale, float* shift, int C, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Encoder block: Conv2d(k5,s2,p2) (+ folded BN + LeakyReLU) -- replaces self.convK(x), model.py:176-181.
+ *   y[b,oh,ow,n] = epi(bias[n] + sum_{kh,kw,c} x[b,2oh-2+kh,2ow-2+kw,c] * wp[n][kh][kw][c])
+ *   epi(v) = v                                  if scale == NULL   (training: raw output for BN stats)
+ *          = leaky(v*scale[n]+shift[n], slope)  otherwise          (eval: BN folded)
+ * Output is (B, (H+1)/2, (W+1)/2, N).  C == 1 (conv1) takes w as wp[25][N] (tap-major).
+ * accumulate != 0 adds into y instead of overwriting it. */
+size_t svs_enc_block_workspace_bytes(int B, int H, int W, int C, int N);
+int svs_enc_block_fwd(const float* x, int64_t ldx, int B, int H, int W, int C,
+                      const float* wp, const float* bias, const float* scale, const float* shift, float slope,
+                      float* y, int64_t ldy, int N, int accumulate,
+                      void* ws, size_t ws_bytes, hipStream_t stream);
+
+/* Decoder block: ConvTranspose2d(k5,s2,p2, output_size=(Ho,Wo)) (+ folded BN + ReLU) -- replaces
+ * self.deconvK(cat, output_size=...), model.py:183-196.  x is the (virtually concatenated) input with
+ * C channels; wp is the parity packing.  Ho in {2H-1, 2H}, Wo in {2W-1, 2W}. */
+size_t svs_dec_block_workspace_bytes(int B, int H, int W, int C, int Ho, int Wo, int N);
+int svs_dec_block_fwd(const float* x, int64_t ldx, int B, int H, int W, int C,
+                      const float* wp, const float* bias, const float* scale, const float* shift, float slope,
+                      float* y, int64_t ldy, int Ho, int Wo, int N, int accumulate,
+                      void* ws, size_t ws_bytes, hipStream_t stream);
+
+/* Output block: deconv6 (C -> 1 channel) + sigmoid -- model.py:198-200.  w is torch's (C,1,5,5)
+ * layout as-is; bias is a device scalar.  y is (B,1,Ho,Wo). */
+int svs_out_block_fwd(const float* x, int64_t ldx, int B, int H, int W, int C,
+                      const float* w, const float* bias, float* y, int Ho, int Wo, int apply_sigmoid,
+                      hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Backward (autograd of the above; the reference gets these from torch at train.py:299).
+ * bwd_data of a conv is a transposed conv with the same weights and vice versa, so:
+ *   svs_enc_block_bwd_data  dx (B,H,W,C) = ConvT(dy (B,Ho,Wo,N));  wpar = parity packing of the Conv2d weight
+ *   svs_dec_block_bwd_data  dx (B,H,W,C) = Conv (dy (B,Ho,Wo,N));  wgat = gather packing of the ConvT weight
+ * N == 1 in svs_dec_block_bwd_data (deconv6) takes w as wp[25][C]. */
+int svs_enc_block_bwd_data(const float* dy, int64_t lddy, int B, int Ho, int Wo, int N, const float* wpar,
+                           float* dx, int64_t lddx, int H, int W, int C, int accumulate,
+                           void* ws, size_t ws_bytes, hipStream_t stream);
+int svs_dec_block_bwd_data(const float* dy, int64_t lddy, int B, int Ho, int Wo, int N, const float* wgat,
+                           float* dx, int64_t lddx, int H, int W, int C, int accumulate,
+                           void* ws, size_t ws_bytes, hipStream_t stream);
+/* Weight gradients, written in torch's layout:
+ *   enc: dw[n][c][kh][kw] = sum_{b,oh,ow} dy[b,oh,ow,n] * x[b,2oh-2+kh,2ow-2+kw,c]      (N,C,5,5)
+ *   dec: dw[c][n][kh][kw] = sum_{b,ih,iw} x[b,ih,iw,c] * dy[b,2ih-2+kh,2iw-2+kw,n]      (C,N,5,5)
+ * and bias gradients db[n] = sum dy[...,n] when db != NULL. */
+size_t svs_block_bwd_weight_workspace_bytes(int B, int Hs, int Ws, int Cs, int Cl);
+int svs_enc_block_bwd_weight(const float* dy, int64_t lddy, int B, int Ho, int Wo, int N,
+                             const float* x, int64_t ldx, int H, int W, int C,
+                             float* dw, float* db, void* ws, size_t ws_bytes, hipStream_t stream);
+int svs_dec_block_bwd_weight(const float* x, int64_t ldx, int B, int H, int W, int C,
+                             const float* dy, int64_t lddy, int Ho, int Wo, int N,
+                             float* dw, float* db, void* ws, size_t ws_bytes, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Training-mode BatchNorm2d + activation (+ Dropout2d) -- model.py:49-50, 81-83 in .train().
+ * raw is the (P = B*H*W, C) conv output.  svs_bn_stats writes per-workgroup partial sums,
+ * svs_bn_finalize turns them into batch mean / 1/sqrt(biased var + eps), updates the running
+ * statistics (momentum, UNBIASED variance) and num_batches_tracked, and svs_bn_act_apply writes
+ * y = leaky((raw-mean)*invstd*gamma+beta, slope) * drop[b][c]   (drop == NULL: no dropout). */
+size_t svs_bn_workspace_bytes(int64_t P, int C);
+int svs_bn_stats(const float* raw, int64_t ldr, int64_t P, int C, void* ws, size_t ws_bytes, hipStream_t stream);
+int svs_bn_finalize(const void* ws, int64_t P, int C, float eps, float momentum,
+                    float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                    float* save_mean, float* save_invstd, hipStream_t stream);
+int svs_bn_act_apply(const float* raw, int64_t ldr, int64_t P, int C, int64_t pixels_per_sample,
+                     const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
+                     float slope, const float* drop, float* y, int64_t ldy, hipStream_t stream);
+/* Backward of (BN -> activation -> dropout): d_raw (P,C contiguous), dgamma, dbeta from dy (grad of y). */
+int svs_bn_bwd(const float* dy, int64_t lddy, const float* raw, int64_t ldr, int64_t P, int C,
+               int64_t pixels_per_sample, const float* gamma, const float* beta,
+               const float* save_mean, const float* save_invstd, float slope, const float* drop,
+               float* d_raw, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Loss of the training step, train.py:274-283 with model.crit = nn.L1Loss() (config.py:33,44):
+ *   loss = mean|mask*mix - voc| + mean|(1-mask)*mix - max(mix-voc,0)|
+ * Writes the UNSCALED loss to *loss (device scalar) and d_logit = loss_scale * dloss/dmask * mask*(1-mask)
+ * (the gradient w.r.t. deconv6's pre-sigmoid output; loss_scale = alpha_L1, train.py:24,296). */
+size_t svs_l1_mask_loss_workspace_bytes(int64_t n);
+int svs_l1_mask_loss_fwd_bwd(const float* mask, const float* mix, const float* voc, int64_t n, float loss_scale,
+                             float* d_logit, float* loss, void* ws, size_t ws_bytes, hipStream_t stream);
+
+/* torch.optim.Adam(lr, betas, eps), no weight decay / amsgrad (model.py:116), over flat buffers.
+ * g is multiplied by grad_scale first (1/world for data-parallel mean). step is 1-based. */
+int svs_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                  float eps, int step, float grad_scale, hipStream_t stream);
+
+/* inference.py:100-107: out = mix * mask, or mix * (1 - mask) when invert != 0. */
+int svs_apply_mask(const float* mix, const float* mask, float* out, int64_t n, int invert, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Whole-network entry points (host-side orchestration in C++; one call per forward / train step).
+ * `params` is the flat fp32 buffer of the 46 trainable tensors in state_dict order (each tensor in
+ * torch's layout; offsets from svs_unet_param_offset), `bn_buffers` the flat running_mean/var of the
+ * 11 BatchNorms in state_dict order (mean then var per layer; offsets from svs_unet_buffer_offset). */
+#define SVS_UNET_NUM_PARAMS 46
+#define SVS_UNET_NUM_BN 11
+int64_t svs_unet_param_offset(int tensor_index);      /* index == SVS_UNET_NUM_PARAMS -> total floats */
+int64_t svs_unet_buffer_offset(int bn_index, int which /*0 mean, 1 var*/);  /* bn_index == 11 -> total */
+
+/* Eval: pack weights + fold BN once per checkpoint, then run forwards. */
+size_t svs_unet_prepared_bytes(void);
+int svs_unet_prepare_eval(const float* params, const float* bn_buffers, void* prepared, hipStream_t stream);
+size_t svs_unet_eval_workspace_bytes(int B, int H, int W);
+/* mask = UNet.forward(mix) in eval mode -- model.py:169-201; mix, mask are (B,1,H,W). */
+int svs_unet_forward_eval(const void* prepared, const float* mix, float* mask, int B, int H, int W,
+                          void* ws, size_t ws_bytes, hipStream_t stream);
+
+/* Train: forward (batch statistics, dropout) + L1 loss + backward, gradients into `grads` (flat,
+ * same layout as params; overwritten).  Running stats in bn_buffers and num_batches_tracked (11
+ * int64) are updated like torch does.  drop: 5 pointers' worth of masks laid out back to back
+ * (B*256, B*128, B*64, B*32, B*16 floats) or NULL for no dropout.  The optimiser step is separate
+ * (svs_adam_step) so that a data-parallel caller can all-reduce `grads` in between.
+ * svs_unet_ws_offset reports where an intermediate lives inside ws (tests read them). */
+size_t svs_unet_train_workspace_bytes(int B, int H, int W);
+int svs_unet_train_fwd_bwd(const float* params, float* grads, float* bn_buffers, int64_t* num_batches_tracked,
+                           const float* mix, const float* voc, const float* drop, int B, int H, int W,
+                           float loss_scale, float* mask /*nullable*/, float* loss,
+                           void* ws, size_t ws_bytes, hipStream_t stream);
+/* Split form used by the autograd Function (train.py calls model(mix), builds the loss in torch and
+ * calls .backward()): forward keeps its intermediates in ws; backward consumes d_mask. */
+int svs_unet_train_forward(const float* params, float* bn_buffers, int64_t* num_batches_tracked,
+                           const float* mix, const float* drop, int B, int H, int W, float* mask,
+                           void* ws, size_t ws_bytes, hipStream_t stream);
+int svs_unet_train_backward(const float* params, float* grads, const float* mix, const float* mask,
+                            const float* d_mask, const float* drop, int B, int H, int W,
+                            void* ws, size_t ws_bytes, hipStream_t stream);
+int64_t svs_unet_ws_offset(const char* name, int B, int H, int W, int training);  /* bytes, <0 unknown */
+
+/* ---------------------------------------------------------------------------------------------
+ * Signal front/back end (replaces librosa.stft / magphase / istft at data.py:79-80,100-101,159 and
+ * torch.istft at train.py:51-58).  n_fft-point periodic-Hann STFT, centred with zero padding,
+ * frames = 1 + n_samples / hop.  mag is (n_fft/2+1, frames) float32 row-major; phase (optional)
+ * is the unit phasor as interleaved (re, im) float32 pairs, 1+0j where the bin is exactly 0. */
+int svs_stft_frames(int64_t n_samples, int hop);
+int svs_stft_fwd(const float* y, int64_t n_samples, int n_fft, int hop, float* mag, float* phase,
+                 hipStream_t stream);
+/* y (hop*(frames-1) samples) = istft(mag * phase), window-sum-square normalised, both n_fft/2 edges
+ * trimmed.  phase_is_angle != 0: phase holds angles in radians (train.py:45 torch.polar), else
+ * interleaved unit phasors (data.py:159). */
+size_t svs_istft_workspace_bytes(int n_fft, int hop, int frames);
+int svs_istft(const float* mag, const float* phase, int phase_is_angle, int n_fft, int hop, int frames,
+              float* y, void* ws, size_t ws_bytes, hipStream_t stream);
+/* data.py:84-85,105 (divide by the mixture's maximum) and data.py:162-164 (peak-normalise to 0.9). */
+int svs_absmax(const float* x, int64_t n, float* out /*device scalar*/, void* ws, size_t ws_bytes, hipStream_t stream);
+int svs_scale_by_inv(float* x, int64_t n, const float* denom /*device scalar; 0 -> 1*/, float numer, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVS_HIP_H */

@@ -1,0 +1,73 @@
+"""Builds libsvs_hip.so (the C-ABI library of hand-written gfx950 kernels) in-tree with hipcc.
+
+    python -m svs_unet_pytorch_amd.build [--force]
+
+hipcc cross-compiles for gfx950 without a GPU; the resulting .so travels to the GPU box with the
+repo snapshot (it is git-ignored, not gpurun-ignored).
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libsvs_hip.so")
+OBJ = os.path.join(HERE, "build")
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _deps():
+    hdr = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdr.append(os.path.join(os.path.dirname(HERE), "include", "svs_hip.h"))
+    return hdr
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(src):
+    obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+    if _stale(obj, [src] + _deps()):
+        cmd = ["hipcc", *FLAGS, "-c", src, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+        if r.stderr.strip():
+            sys.stderr.write(r.stderr)
+    return obj
+
+
+def build_lib(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = sources()
+    if force:
+        for f in os.listdir(OBJ):
+            os.remove(os.path.join(OBJ, f))
+    with ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
+        objs = list(ex.map(_compile, srcs))
+    if force or _stale(LIB, objs):
+        cmd = ["hipcc", f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        if verbose:
+            print(f"built {LIB}")
+    elif verbose:
+        print(f"{LIB} is up to date")
+    return LIB
+
+
+if __name__ == "__main__":
+    build_lib(force="--force" in sys.argv)

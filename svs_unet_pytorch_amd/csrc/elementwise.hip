@@ -1,0 +1,529 @@
+// Bandwidth-bound pieces of the training / inference step (gfx950): BatchNorm statistics, finalise,
+// apply (+ LeakyReLU/ReLU + Dropout2d), BatchNorm backward, the L1 mask loss, Adam, weight packing,
+// eval-mode BN folding, synthetic data.  All tensors are fp32 NHWC (pixel-major), read and written
+// as float4 by C/4 adjacent lanes per pixel.  Bound: HBM (each tensor once per pass).
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// per-channel block reduction shared by bn_stats (sum x, sum x^2) and bn_bwd (sum dz, sum dz*xhat)
+// partial layout: ws[blk][2][C]
+// ------------------------------------------------------------------------------------------------
+static inline int red_blocks(long P, int C) {
+  long nb = (P * C) / 16384;
+  if (nb > 1024) nb = 1024;
+  if (nb < 1) nb = 1;
+  return (int)nb;
+}
+
+struct BnCtx {
+  const float* raw; long ldr; long P; int C; long pps;    // pps: pixels per sample (dropout index)
+  const float* gamma; const float* beta; const float* mean; const float* invstd;
+  float slope; const float* drop;
+  const float* dy; long lddy;
+};
+
+// MODE 0: stats of raw.  MODE 1: backward sums.
+template <int MODE>
+__global__ __launch_bounds__(256) void channel_reduce_kernel(BnCtx p, float* __restrict__ partial, long pix_per_block) {
+  __shared__ f32x4 red[2][256];
+  const int G = p.C >> 2;
+  const int t = threadIdx.x;
+  const int cg = t % G, pl = t / G;
+  const int PL = 256 / G;
+  const long p0 = (long)blockIdx.x * pix_per_block;
+  long p1 = p0 + pix_per_block;
+  if (p1 > p.P) p1 = p.P;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 mean4, k4, beta4, inv4;
+  if (MODE == 1) {
+    mean4 = *(const f32x4*)(p.mean + cg * 4);
+    inv4 = *(const f32x4*)(p.invstd + cg * 4);
+    k4 = *(const f32x4*)(p.gamma + cg * 4) * inv4;
+    beta4 = *(const f32x4*)(p.beta + cg * 4);
+  }
+  if (pl < PL) {
+    for (long pix = p0 + pl; pix < p1; pix += PL) {
+      const f32x4 x = *(const f32x4*)(p.raw + pix * p.ldr + cg * 4);
+      if (MODE == 0) {
+        s0 += x;
+        s1 += x * x;
+      } else {
+        f32x4 dz = *(const f32x4*)(p.dy + pix * p.lddy + cg * 4);
+        if (p.drop) dz *= *(const f32x4*)(p.drop + (pix / p.pps) * p.C + cg * 4);
+        const f32x4 xm = x - mean4;
+        const f32x4 z = xm * k4 + beta4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dz[k] = z[k] > 0.f ? dz[k] : dz[k] * p.slope;
+        s0 += dz;
+        s1 += dz * (xm * inv4);
+      }
+    }
+  }
+  red[0][t] = s0;
+  red[1][t] = s1;
+  __syncthreads();
+  if (t < G) {
+    f32x4 a = red[0][t], b = red[1][t];
+    for (int j = 1; j < PL; ++j) { a += red[0][j * G + t]; b += red[1][j * G + t]; }
+    float* out = partial + (long)blockIdx.x * 2 * p.C;
+    *(f32x4*)(out + t * 4) = a;
+    *(f32x4*)(out + p.C + t * 4) = b;
+  }
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ partial, int nblk, long P, int C, float eps, float momentum,
+                                   float* running_mean, float* running_var, long long* nbt, float* save_mean,
+                                   float* save_invstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && nbt) nbt[0] += 1;
+  if (c >= C) return;
+  double s = 0.0, ss = 0.0;
+  for (int b = 0; b < nblk; ++b) {
+    s += (double)partial[(long)b * 2 * C + c];
+    ss += (double)partial[(long)b * 2 * C + C + c];
+  }
+  const double mean = s / (double)P;
+  double var = ss / (double)P - mean * mean;
+  if (var < 0.0) var = 0.0;
+  save_mean[c] = (float)mean;
+  save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) {
+    const double unb = P > 1 ? var * ((double)P / (double)(P - 1)) : var;
+    running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+    running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_act_apply_kernel(BnCtx p, float* __restrict__ y, long ldy) {
+  const int G = p.C >> 2;
+  const long total = p.P * G;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int cg = (int)(i % G);
+    const long pix = i / G;
+    const f32x4 x = *(const f32x4*)(p.raw + pix * p.ldr + cg * 4);
+    const f32x4 k4 = *(const f32x4*)(p.gamma + cg * 4) * *(const f32x4*)(p.invstd + cg * 4);
+    f32x4 z = (x - *(const f32x4*)(p.mean + cg * 4)) * k4 + *(const f32x4*)(p.beta + cg * 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) z[k] = z[k] > 0.f ? z[k] : z[k] * p.slope;
+    if (p.drop) z *= *(const f32x4*)(p.drop + (pix / p.pps) * p.C + cg * 4);
+    *(f32x4*)(y + pix * ldy + cg * 4) = z;
+  }
+}
+
+// coef[0][c] = gamma*invstd, coef[1][c] = mean(dz), coef[2][c] = mean(dz*xhat)
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, long P, int C,
+                                       const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                       float* dgamma, float* dbeta, float* coef) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, sx = 0.0;
+  for (int b = 0; b < nblk; ++b) {
+    s += (double)partial[(long)b * 2 * C + c];
+    sx += (double)partial[(long)b * 2 * C + C + c];
+  }
+  if (dbeta) dbeta[c] = (float)s;
+  if (dgamma) dgamma[c] = (float)sx;
+  coef[c] = gamma[c] * invstd[c];
+  coef[C + c] = (float)(s / (double)P);
+  coef[2 * C + c] = (float)(sx / (double)P);
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnCtx p, const float* __restrict__ coef, float* __restrict__ d_raw) {
+  const int G = p.C >> 2;
+  const long total = p.P * G;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int cg = (int)(i % G);
+    const long pix = i / G;
+    const f32x4 x = *(const f32x4*)(p.raw + pix * p.ldr + cg * 4);
+    f32x4 dz = *(const f32x4*)(p.dy + pix * p.lddy + cg * 4);
+    if (p.drop) dz *= *(const f32x4*)(p.drop + (pix / p.pps) * p.C + cg * 4);
+    const f32x4 inv4 = *(const f32x4*)(p.invstd + cg * 4);
+    const f32x4 k4 = *(const f32x4*)(coef + cg * 4);
+    const f32x4 xm = x - *(const f32x4*)(p.mean + cg * 4);
+    const f32x4 z = xm * k4 + *(const f32x4*)(p.beta + cg * 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dz[k] = z[k] > 0.f ? dz[k] : dz[k] * p.slope;
+    const f32x4 r = k4 * (dz - *(const f32x4*)(coef + p.C + cg * 4) - (xm * inv4) * *(const f32x4*)(coef + 2 * p.C + cg * 4));
+    *(f32x4*)(d_raw + pix * p.C + cg * 4) = r;
+  }
+}
+
+static int check_bn(const char* who, const float* raw, long ldr, long P, int C) {
+  SVS_REQUIRE(raw, "%s: null pointer", who);
+  SVS_REQUIRE(C >= 4 && C % 4 == 0 && C <= 1024 && (256 % (C / 4) == 0 || (C / 4) % 256 == 0), "%s: unsupported C=%d", who, C);
+  SVS_REQUIRE(P > 0 && ldr >= C && ldr % 4 == 0 && svs_aligned16(raw), "%s: bad view", who);
+  return SVS_OK;
+}
+
+static int grid_for(long total) {
+  long g = (total + 255) / 256;
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+extern "C" size_t svs_bn_workspace_bytes(int64_t P, int C) {
+  return (size_t)red_blocks(P, C) * 2 * C * sizeof(float) + (size_t)3 * C * sizeof(float);
+}
+
+extern "C" int svs_bn_stats(const float* raw, int64_t ldr, int64_t P, int C, void* ws, size_t ws_bytes, hipStream_t stream) {
+  int rc = check_bn("svs_bn_stats", raw, ldr, P, C);
+  if (rc) return rc;
+  if (!ws || ws_bytes < svs_bn_workspace_bytes(P, C)) { svs_set_error("svs_bn_stats: workspace too small"); return SVS_ERR_WORKSPACE; }
+  const int nb = red_blocks(P, C);
+  BnCtx p{}; p.raw = raw; p.ldr = ldr; p.P = P; p.C = C;
+  hipLaunchKernelGGL(channel_reduce_kernel<0>, dim3(nb), dim3(256), 0, stream, p, (float*)ws, (P + nb - 1) / nb);
+  SVS_CHECK_LAUNCH("bn_stats");
+  return SVS_OK;
+}
+
+extern "C" int svs_bn_finalize(const void* ws, int64_t P, int C, float eps, float momentum, float* running_mean,
+                               float* running_var, int64_t* num_batches_tracked, float* save_mean, float* save_invstd,
+                               hipStream_t stream) {
+  SVS_REQUIRE(ws && save_mean && save_invstd, "svs_bn_finalize: null pointer");
+  const int nb = red_blocks(P, C);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, (const float*)ws, nb, (long)P, C, eps,
+                     momentum, running_mean, running_var, (long long*)num_batches_tracked, save_mean, save_invstd);
+  SVS_CHECK_LAUNCH("bn_finalize");
+  return SVS_OK;
+}
+
+extern "C" int svs_bn_act_apply(const float* raw, int64_t ldr, int64_t P, int C, int64_t pixels_per_sample,
+                                const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
+                                float slope, const float* drop, float* y, int64_t ldy, hipStream_t stream) {
+  int rc = check_bn("svs_bn_act_apply", raw, ldr, P, C);
+  if (rc) return rc;
+  SVS_REQUIRE(y && ldy >= C && ldy % 4 == 0 && svs_aligned16(y), "svs_bn_act_apply: bad output view");
+  BnCtx p{}; p.raw = raw; p.ldr = ldr; p.P = P; p.C = C; p.pps = pixels_per_sample;
+  p.gamma = gamma; p.beta = beta; p.mean = save_mean; p.invstd = save_invstd; p.slope = slope; p.drop = drop;
+  hipLaunchKernelGGL(bn_act_apply_kernel, dim3(grid_for(P * (C / 4))), dim3(256), 0, stream, p, y, (long)ldy);
+  SVS_CHECK_LAUNCH("bn_act_apply");
+  return SVS_OK;
+}
+
+extern "C" int svs_bn_bwd(const float* dy, int64_t lddy, const float* raw, int64_t ldr, int64_t P, int C,
+                          int64_t pixels_per_sample, const float* gamma, const float* beta, const float* save_mean,
+                          const float* save_invstd, float slope, const float* drop, float* d_raw, float* dgamma,
+                          float* dbeta, void* ws, size_t ws_bytes, hipStream_t stream) {
+  int rc = check_bn("svs_bn_bwd", raw, ldr, P, C);
+  if (rc) return rc;
+  SVS_REQUIRE(dy && d_raw && lddy >= C && lddy % 4 == 0 && svs_aligned16(dy) && svs_aligned16(d_raw), "svs_bn_bwd: bad gradient view");
+  if (!ws || ws_bytes < svs_bn_workspace_bytes(P, C)) { svs_set_error("svs_bn_bwd: workspace too small"); return SVS_ERR_WORKSPACE; }
+  const int nb = red_blocks(P, C);
+  float* partial = (float*)ws;
+  float* coef = partial + (size_t)nb * 2 * C;
+  BnCtx p{}; p.raw = raw; p.ldr = ldr; p.P = P; p.C = C; p.pps = pixels_per_sample;
+  p.gamma = gamma; p.beta = beta; p.mean = save_mean; p.invstd = save_invstd; p.slope = slope; p.drop = drop;
+  p.dy = dy; p.lddy = lddy;
+  hipLaunchKernelGGL(channel_reduce_kernel<1>, dim3(nb), dim3(256), 0, stream, p, partial, (P + nb - 1) / nb);
+  SVS_CHECK_LAUNCH("bn_bwd_reduce");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, (const float*)partial, nb, (long)P, C,
+                     gamma, save_invstd, dgamma, dbeta, coef);
+  SVS_CHECK_LAUNCH("bn_bwd_finalize");
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(P * (C / 4))), dim3(256), 0, stream, p, (const float*)coef, d_raw);
+  SVS_CHECK_LAUNCH("bn_bwd_apply");
+  return SVS_OK;
+}
+
+// per-channel sum of a (P, C) view -> out[C]   (bias gradients).  Uses the stats kernel's partials.
+int svs_channel_sum_run(const float* x, long ldx, long P, int C, float* out, void* ws, size_t ws_bytes, hipStream_t stream);
+
+__global__ void channel_sum_finalize_kernel(const float* __restrict__ partial, int nblk, int C, float* out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int b = 0; b < nblk; ++b) s += (double)partial[(long)b * 2 * C + c];
+  out[c] = (float)s;
+}
+
+int svs_channel_sum_run(const float* x, long ldx, long P, int C, float* out, void* ws, size_t ws_bytes, hipStream_t stream) {
+  int rc = svs_bn_stats(x, ldx, P, C, ws, ws_bytes, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, (const float*)ws, red_blocks(P, C), C, out);
+  SVS_CHECK_LAUNCH("channel_sum_finalize");
+  return SVS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// scalar reductions: two-stage, fixed order
+// ------------------------------------------------------------------------------------------------
+#define SCALAR_BLOCKS 512
+
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+  v = svs_wave_sum(v);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+  __syncthreads();
+  return r;
+}
+
+__global__ __launch_bounds__(256) void l1_mask_loss_kernel(const float* __restrict__ mask, const float* __restrict__ mix,
+                                                           const float* __restrict__ voc, long n, float gscale,
+                                                           float* __restrict__ d_logit, float* __restrict__ partial) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float m = mask[i], x = mix[i], v = voc[i];
+    const float d1 = m * x - v;
+    const float ta = fmaxf(x - v, 0.f);
+    const float d2 = (1.f - m) * x - ta;
+    s += fabsf(d1) + fabsf(d2);
+    const float s1 = d1 > 0.f ? 1.f : (d1 < 0.f ? -1.f : 0.f);
+    const float s2 = d2 > 0.f ? 1.f : (d2 < 0.f ? -1.f : 0.f);
+    const float dm = (s1 - s2) * x * gscale;
+    d_logit[i] = dm * m * (1.f - m);
+  }
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+__global__ void sum_partials_kernel(const float* __restrict__ partial, int nb, double scale, float* out) {
+  __shared__ double sh[64];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nb; i += 64) s += (double)partial[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tsum = 0.0;
+    for (int i = 0; i < 64; ++i) tsum += sh[i];
+    out[0] = (float)(tsum * scale);
+  }
+}
+
+extern "C" size_t svs_l1_mask_loss_workspace_bytes(int64_t n) { (void)n; return SCALAR_BLOCKS * sizeof(float); }
+
+extern "C" int svs_l1_mask_loss_fwd_bwd(const float* mask, const float* mix, const float* voc, int64_t n, float loss_scale,
+                                        float* d_logit, float* loss, void* ws, size_t ws_bytes, hipStream_t stream) {
+  SVS_REQUIRE(mask && mix && voc && d_logit && loss && n > 0, "svs_l1_mask_loss_fwd_bwd: null pointer");
+  if (!ws || ws_bytes < SCALAR_BLOCKS * sizeof(float)) { svs_set_error("svs_l1_mask_loss_fwd_bwd: workspace too small"); return SVS_ERR_WORKSPACE; }
+  int nb = (int)((n + 255) / 256);
+  if (nb > SCALAR_BLOCKS) nb = SCALAR_BLOCKS;
+  hipLaunchKernelGGL(l1_mask_loss_kernel, dim3(nb), dim3(256), 0, stream, mask, mix, voc, (long)n, loss_scale / (float)n, d_logit, (float*)ws);
+  SVS_CHECK_LAUNCH("l1_mask_loss");
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, stream, (const float*)ws, nb, 1.0 / (double)n, loss);
+  SVS_CHECK_LAUNCH("sum_partials");
+  return SVS_OK;
+}
+
+// d_logit = d_mask * mask * (1 - mask)    (autograd path: the loss was built by the caller in torch)
+__global__ __launch_bounds__(256) void sigmoid_bwd_kernel(const float* __restrict__ mask, const float* __restrict__ dmask,
+                                                          long n, float* __restrict__ d_logit) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float m = mask[i];
+    d_logit[i] = dmask[i] * m * (1.f - m);
+  }
+}
+int svs_sigmoid_bwd_run(const float* mask, const float* dmask, long n, float* d_logit, hipStream_t stream) {
+  hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, stream, mask, dmask, n, d_logit);
+  SVS_CHECK_LAUNCH("sigmoid_bwd");
+  return SVS_OK;
+}
+
+__global__ __launch_bounds__(256) void sum_kernel(const float* __restrict__ x, long n, float* __restrict__ partial) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) s += x[i];
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+// out[0] = sum(x); ws: SCALAR_BLOCKS floats
+int svs_sum_run(const float* x, long n, float* out, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (!ws || ws_bytes < SCALAR_BLOCKS * sizeof(float)) { svs_set_error("svs_sum: workspace too small"); return SVS_ERR_WORKSPACE; }
+  int nb = (int)((n + 255) / 256);
+  if (nb > SCALAR_BLOCKS) nb = SCALAR_BLOCKS;
+  hipLaunchKernelGGL(sum_kernel, dim3(nb), dim3(256), 0, stream, x, n, (float*)ws);
+  SVS_CHECK_LAUNCH("sum");
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, stream, (const float*)ws, nb, 1.0, out);
+  SVS_CHECK_LAUNCH("sum_partials");
+  return SVS_OK;
+}
+
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long n, float* __restrict__ partial) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) s = fmaxf(s, fabsf(x[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s = fmaxf(s, __shfl_xor(s, o, 64));
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+__global__ void max_partials_kernel(const float* __restrict__ partial, int nb, float* out) {
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nb; i += 64) s = fmaxf(s, partial[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s = fmaxf(s, __shfl_xor(s, o, 64));
+  if (threadIdx.x == 0) out[0] = s;
+}
+extern "C" int svs_absmax(const float* x, int64_t n, float* out, void* ws, size_t ws_bytes, hipStream_t stream) {
+  SVS_REQUIRE(x && out && n > 0, "svs_absmax: null pointer");
+  if (!ws || ws_bytes < SCALAR_BLOCKS * sizeof(float)) { svs_set_error("svs_absmax: workspace too small"); return SVS_ERR_WORKSPACE; }
+  int nb = (int)((n + 255) / 256);
+  if (nb > SCALAR_BLOCKS) nb = SCALAR_BLOCKS;
+  hipLaunchKernelGGL(absmax_kernel, dim3(nb), dim3(256), 0, stream, x, (long)n, (float*)ws);
+  SVS_CHECK_LAUNCH("absmax");
+  hipLaunchKernelGGL(max_partials_kernel, dim3(1), dim3(64), 0, stream, (const float*)ws, nb, out);
+  SVS_CHECK_LAUNCH("max_partials");
+  return SVS_OK;
+}
+
+__global__ __launch_bounds__(256) void scale_by_inv_kernel(float* x, long n, const float* denom, float numer) {
+  float d = denom[0];
+  if (d == 0.f) d = 1.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) x[i] = x[i] / d * numer;
+}
+extern "C" int svs_scale_by_inv(float* x, int64_t n, const float* denom, float numer, hipStream_t stream) {
+  SVS_REQUIRE(x && denom && n > 0, "svs_scale_by_inv: null pointer");
+  hipLaunchKernelGGL(scale_by_inv_kernel, dim3(grid_for(n)), dim3(256), 0, stream, x, (long)n, denom, numer);
+  SVS_CHECK_LAUNCH("scale_by_inv");
+  return SVS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Adam (torch.optim.Adam single-tensor update, model.py:116)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long n, float b1, float b2, float eps,
+                                                   float step_size, float bc2_sqrt, float gscale) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float gi = g[i] * gscale;
+    const float mi = m[i] * b1 + (1.f - b1) * gi;
+    const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] -= step_size * (mi / denom);
+  }
+}
+extern "C" int svs_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                             float eps, int step, float grad_scale, hipStream_t stream) {
+  SVS_REQUIRE(p && g && m && v && n > 0 && step >= 1, "svs_adam_step: bad arguments");
+  const double bc1 = 1.0 - pow((double)beta1, step);
+  const double bc2 = 1.0 - pow((double)beta2, step);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, stream, p, g, m, v, (long)n, beta1, beta2, eps,
+                     (float)((double)lr / bc1), (float)sqrt(bc2), grad_scale);
+  SVS_CHECK_LAUNCH("adam");
+  return SVS_OK;
+}
+
+__global__ __launch_bounds__(256) void apply_mask_kernel(const float* __restrict__ mix, const float* __restrict__ mask,
+                                                         float* __restrict__ out, long n, int invert) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float m = mask[i];
+    if (invert) m = 1.f - m;
+    out[i] = mix[i] * m;
+  }
+}
+extern "C" int svs_apply_mask(const float* mix, const float* mask, float* out, int64_t n, int invert, hipStream_t stream) {
+  SVS_REQUIRE(mix && mask && out && n > 0, "svs_apply_mask: null pointer");
+  hipLaunchKernelGGL(apply_mask_kernel, dim3(grid_for(n)), dim3(256), 0, stream, mix, mask, out, (long)n, invert);
+  SVS_CHECK_LAUNCH("apply_mask");
+  return SVS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing / BN fold / synthetic data
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_gather_kernel(const float* __restrict__ w, float* __restrict__ wp, int N, int C) {
+  const long total = (long)N * C * 25;
+  for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < total; o += (long)gridDim.x * 256) {
+    const int c = (int)(o % C);
+    const long r = o / C;
+    const int tap = (int)(r % 25);
+    const long n = r / 25;
+    wp[o] = w[(n * C + c) * 25 + tap];
+  }
+}
+extern "C" int svs_pack_weight_gather(const float* w, float* wp, int N, int C, hipStream_t stream) {
+  SVS_REQUIRE(w && wp && N > 0 && C > 0, "svs_pack_weight_gather: bad arguments");
+  hipLaunchKernelGGL(pack_gather_kernel, dim3(grid_for((long)N * C * 25)), dim3(256), 0, stream, w, wp, N, C);
+  SVS_CHECK_LAUNCH("pack_gather");
+  return SVS_OK;
+}
+
+__global__ __launch_bounds__(256) void pack_parity_kernel(const float* __restrict__ w, float* __restrict__ wp, int C, int N) {
+  const long total = (long)N * C * 25;
+  const long NC = (long)N * C;
+  for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < total; o += (long)gridDim.x * 256) {
+    int par; long rem;
+    if (o < 9 * NC) { par = 0; rem = o; }
+    else if (o < 15 * NC) { par = 1; rem = o - 9 * NC; }
+    else if (o < 21 * NC) { par = 2; rem = o - 15 * NC; }
+    else { par = 3; rem = o - 21 * NC; }
+    const int ph = par >> 1, pw = par & 1;
+    const int ntw = 3 - pw, ntaps = (3 - ph) * ntw;
+    const int c = (int)(rem % C);
+    const long r = rem / C;
+    const int tap = (int)(r % ntaps);
+    const long n = r / ntaps;
+    const int th = tap / ntw, tw = tap - th * ntw;
+    const int kh = ph + 2 * th, kw = pw + 2 * tw;
+    wp[o] = w[((long)c * N + n) * 25 + kh * 5 + kw];
+  }
+}
+extern "C" int svs_pack_weight_parity(const float* w, float* wp, int C, int N, hipStream_t stream) {
+  SVS_REQUIRE(w && wp && N > 0 && C > 0, "svs_pack_weight_parity: bad arguments");
+  hipLaunchKernelGGL(pack_parity_kernel, dim3(grid_for((long)N * C * 25)), dim3(256), 0, stream, w, wp, C, N);
+  SVS_CHECK_LAUNCH("pack_parity");
+  return SVS_OK;
+}
+
+__global__ void bn_fold_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, const float* bias,
+                               float eps, float* scale, float* shift, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float s = gamma[c] / sqrtf(rv[c] + eps);
+  scale[c] = s;
+  shift[c] = beta[c] + ((bias ? bias[c] : 0.f) - rm[c]) * s;
+}
+extern "C" int svs_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                           const float* conv_bias, float eps, float* scale, float* shift, int C, hipStream_t stream) {
+  SVS_REQUIRE(gamma && beta && running_mean && running_var && scale && shift && C > 0, "svs_bn_fold: bad arguments");
+  hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, gamma, beta, running_mean, running_var,
+                     conv_bias, eps, scale, shift, C);
+  SVS_CHECK_LAUNCH("bn_fold");
+  return SVS_OK;
+}
+
+__global__ __launch_bounds__(256) void fill_uniform_kernel(float* out, long n, uint32_t seed, uint64_t offset, float scale, float shift) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+    out[i] = (float)(svs_u32(seed, offset + (uint64_t)i) >> 8) * 5.9604644775390625e-08f * scale + shift;
+}
+extern "C" int svs_fill_uniform(float* out, int64_t n, uint32_t seed, uint64_t offset, float scale, float shift, hipStream_t stream) {
+  SVS_REQUIRE(out && n > 0, "svs_fill_uniform: bad arguments");
+  hipLaunchKernelGGL(fill_uniform_kernel, dim3(grid_for(n)), dim3(256), 0, stream, out, (long)n, seed, offset, scale, shift);
+  SVS_CHECK_LAUNCH("fill_uniform");
+  return SVS_OK;
+}
+
+__global__ __launch_bounds__(256) void fill_tiles_kernel(float* mix, float* voc, long per, long total, long first_tile) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long b = i / per;
+    const uint64_t ctr = (uint64_t)(i - b * per) + ((uint64_t)(first_tile + b) << 32);
+    const float m = (float)(svs_u32(0u, ctr) >> 8) * 5.9604644775390625e-08f;
+    const float r = (float)(svs_u32(1u, ctr) >> 8) * 5.9604644775390625e-08f;
+    mix[i] = m;
+    voc[i] = m * r;
+  }
+}
+extern "C" int svs_fill_tiles(float* mix, float* voc, int B, int H, int W, int64_t first_tile, hipStream_t stream) {
+  SVS_REQUIRE(mix && voc && B > 0 && H > 0 && W > 0, "svs_fill_tiles: bad arguments");
+  const long per = (long)H * W, total = per * B;
+  hipLaunchKernelGGL(fill_tiles_kernel, dim3(grid_for(total)), dim3(256), 0, stream, mix, voc, per, total, (long)first_tile);
+  SVS_CHECK_LAUNCH("fill_tiles");
+  return SVS_OK;
+}
+
+__global__ void dropout_mask_kernel(float* out, int n, uint32_t seed, uint64_t offset) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (float)(svs_u32(seed, offset + (uint64_t)i) >> 31) * 2.f;
+}
+extern "C" int svs_dropout_mask(float* out, int B, int C, int layer, uint32_t seed, int step, int rank, hipStream_t stream) {
+  SVS_REQUIRE(out && B > 0 && C > 0 && layer >= 0 && layer < 5, "svs_dropout_mask: bad arguments");
+  const uint64_t off = ((uint64_t)layer << 56) | ((uint64_t)(rank & 0xFF) << 48) | ((uint64_t)(step & 0xFFFFFF) << 24);
+  const int n = B * C;
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, out, n, seed, off);
+  SVS_CHECK_LAUNCH("dropout_mask");
+  return SVS_OK;
+}

@@ -1,0 +1,365 @@
+// Implicit-GEMM 5x5 / stride-2 convolutions on the fp32 MFMA (v_mfma_f32_16x16x4_f32), gfx950.
+//
+// Two index maps share one kernel (MODE):
+//   MODE_GATHER  y[b,oh,ow,n] = sum_{kh,kw,c} x[b,2oh-2+kh,2ow-2+kw,c] * wp[n][kh][kw][c]
+//                -> Conv2d forward (reference model.py:48-74) and ConvTranspose2d backward-data.
+//   MODE_PARITY  y[b,2a+ph,2c+pw,n] = sum_{th,tw,c} x[b,a+1-th,c+1-tw,c] * wp[p][n][th][tw][c]
+//                (blockIdx.y = p = 2*ph+pw, 9/6/6/4 taps: the four stride-1 sub-convolutions of a
+//                stride-2 transposed conv) -> ConvTranspose2d forward (model.py:79-109) and Conv2d
+//                backward-data.
+// GEMM view: M = output pixels of the (parity) grid, N = output channels, K = taps x input channels,
+// K-tile = 16 consecutive input channels of one tap (NHWC makes them one 64-byte run in HBM).
+//
+// Workgroup: 256 threads = 4 waves arranged WM x WN; each wave owns (BM/WM) x (BN/WN) outputs as
+// 16x16 MFMA tiles.  A (im2col rows) and B (weights) K-tiles are register-staged into LDS (16-byte
+// global loads, XOR-swizzled 64-byte LDS rows so the ds_read_b128 fragment reads are conflict-free),
+// double-buffered with one barrier per K-tile.  Each lane reads 4 consecutive k of its row with one
+// ds_read_b128 and feeds them to 4 MFMAs: lane (row, q) supplies k = 4q+j to MFMA j on both the A and
+// the B side, so the K order inside a tile is permuted consistently and no shuffles are needed.
+//
+// Bound: MFMA (fp32 157.3 TFLOP/s peak); algorithmic FLOPs = 2*M*N*K.
+#include "common.h"
+
+enum { MODE_GATHER = 0, MODE_PARITY = 1 };
+
+struct ConvGemmArgs {
+  const float* x; long ldx;
+  int B, H, W, C;                 // input geometry; C = channels reduced over
+  const float* wp;                // packed weights (see header)
+  const float* bias;              // [N] or null
+  const float* scale;             // [N] or null: epilogue v*scale+shift then leaky(slope)
+  const float* shift;
+  float slope;
+  float* y; long ldy;
+  int Ho, Wo, N;
+  int accumulate;
+  int ksplit;                     // gridDim.z
+  float* slab;                    // [ksplit][B*Ho*Wo][N] partial sums when ksplit > 1
+};
+
+__device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 3); }
+
+template <int MODE, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs p) {
+  constexpr int TM = BM / WM / 16;
+  constexpr int TN = BN / WN / 16;
+  constexpr int RA = (BM + 63) / 64;   // A rows staged per thread
+  constexpr int RB = (BN + 63) / 64;
+  static_assert(WM * WN == 4, "4 waves");
+  static_assert(TM >= 1 && TN >= 1, "tile");
+
+  __shared__ __attribute__((aligned(16))) float As[2][BM * 16];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BN * 16];
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int lrow = lane & 15, q = lane >> 4;
+
+  // ---- geometry of this block ---------------------------------------------------------------
+  int ph = 0, pw = 0, nth = 5, ntw = 5;
+  int Ha, Wa;                      // rows / cols of the M grid
+  const float* wp = p.wp;
+  if (MODE == MODE_PARITY) {
+    const int par = blockIdx.y;
+    ph = par >> 1; pw = par & 1;
+    nth = 3 - ph; ntw = 3 - pw;
+    Ha = (p.Ho - ph + 1) >> 1; Wa = (p.Wo - pw + 1) >> 1;
+    const int poff = (par == 0) ? 0 : (par == 1) ? 9 : (par == 2) ? 15 : 21;
+    wp += (long)poff * p.N * p.C;
+  } else {
+    Ha = p.Ho; Wa = p.Wo;
+  }
+  const int ntaps = nth * ntw;
+  const long M = (long)p.B * Ha * Wa;
+  const int ntile_n = p.N / BN;
+  const long m0 = (long)(blockIdx.x / ntile_n) * BM;
+  const int n0 = (blockIdx.x % ntile_n) * BN;
+  if (m0 >= M) return;             // parity classes of odd-sized outputs are smaller
+  const int cpt = p.C >> 4;        // K-tiles per tap
+  const int nkt = ntaps * cpt;
+  const int kt_begin = (int)((long)nkt * blockIdx.z / p.ksplit);
+  const int kt_end = (int)((long)nkt * (blockIdx.z + 1) / p.ksplit);
+  const long Kw = (long)ntaps * p.C;   // weight row length
+
+  // ---- per-thread staging rows -----------------------------------------------------------------
+  const int chunk = t & 3;
+  int a_h[RA], a_w[RA];             // GATHER: 2oh-2, 2ow-2 ; PARITY: a+1, c+1
+  long a_img[RA];                   // pixel index of (b, 0, 0)
+  bool a_ok[RA];
+#pragma unroll
+  for (int r = 0; r < RA; ++r) {
+    const int row = (t >> 2) + 64 * r;
+    const long m = m0 + row;
+    a_ok[r] = (row < BM) && (m < M);
+    const long mm = a_ok[r] ? m : 0;
+    const int wq = (int)(mm % Wa);
+    const long tmp = mm / Wa;
+    const int hq = (int)(tmp % Ha);
+    const int b = (int)(tmp / Ha);
+    a_img[r] = (long)b * p.H * p.W;
+    if (MODE == MODE_GATHER) { a_h[r] = 2 * hq - 2; a_w[r] = 2 * wq - 2; }
+    else { a_h[r] = hq + 1; a_w[r] = wq + 1; }
+  }
+  const float* b_row[RB];
+  bool b_ok[RB];
+#pragma unroll
+  for (int r = 0; r < RB; ++r) {
+    const int row = (t >> 2) + 64 * r;
+    b_ok[r] = row < BN;
+    b_row[r] = wp + (long)(n0 + (b_ok[r] ? row : 0)) * Kw + chunk * 4;
+  }
+
+  f32x4 ra[RA], rb[RB];
+  auto load_tile = [&](int kt) {
+    const int tap = kt / cpt;
+    const int c0 = (kt - tap * cpt) << 4;
+    const int th = tap / ntw, tw = tap - th * ntw;
+#pragma unroll
+    for (int r = 0; r < RA; ++r) {
+      const int ih = (MODE == MODE_GATHER) ? a_h[r] + th : a_h[r] - th;
+      const int iw = (MODE == MODE_GATHER) ? a_w[r] + tw : a_w[r] - tw;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (a_ok[r] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
+        v = *(const f32x4*)(p.x + (a_img[r] + (long)ih * p.W + iw) * p.ldx + c0 + chunk * 4);
+      ra[r] = v;
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (b_ok[r]) v = *(const f32x4*)(b_row[r] + (long)kt * 16);
+      rb[r] = v;
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int r = 0; r < RA; ++r) {
+      const int row = (t >> 2) + 64 * r;
+      if (row < BM) *(f32x4*)(&As[buf][row * 16 + swz(row, chunk) * 4]) = ra[r];
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const int row = (t >> 2) + 64 * r;
+      if (row < BN) *(f32x4*)(&Bs[buf][row * 16 + swz(row, chunk) * 4]) = rb[r];
+    }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (kt_begin < kt_end) {
+    load_tile(kt_begin);
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int buf = (kt - kt_begin) & 1;
+    const bool more = kt + 1 < kt_end;
+    if (more) load_tile(kt + 1);
+    f32x4 fa[TM], fb[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int row = wm * (TM * 16) + i * 16 + lrow;
+      fa[i] = *(const f32x4*)(&As[buf][row * 16 + swz(row, q) * 4]);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int row = wn * (TN * 16) + j * 16 + lrow;
+      fb[j] = *(const f32x4*)(&Bs[buf][row * 16 + swz(row, q) * 4]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][k], fb[j][k], acc[i][j], 0, 0, 0);
+    if (more) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D map of the 16x16 MFMA: col = lane & 15, row = 4*(lane>>4) + reg ------------
+  const bool split = p.ksplit > 1;
+  float* const slab = split ? p.slab + (long)blockIdx.z * ((long)p.B * p.Ho * p.Wo) * p.N : nullptr;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long m = m0 + wm * (TM * 16) + i * 16 + q * 4 + r;
+      if (m >= M) continue;
+      long opix;
+      if (MODE == MODE_GATHER) {
+        opix = m;
+      } else {
+        const int wq = (int)(m % Wa);
+        const long tmp = m / Wa;
+        const int hq = (int)(tmp % Ha);
+        const long b = tmp / Ha;
+        opix = (b * p.Ho + 2 * hq + ph) * p.Wo + 2 * wq + pw;
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (TN * 16) + j * 16 + lrow;
+        float v = acc[i][j][r];
+        if (split) {
+          slab[opix * p.N + n] = v;
+        } else {
+          if (p.bias) v += p.bias[n];
+          if (p.scale) {
+            v = v * p.scale[n] + p.shift[n];
+            v = v > 0.f ? v : v * p.slope;
+          }
+          float* dst = p.y + opix * p.ldy + n;
+          if (p.accumulate) v += *dst;
+          *dst = v;
+        }
+      }
+    }
+  }
+}
+
+// out[pix][n] = epi(sum_z slab[z][pix][n] + bias[n])
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __restrict__ slab, int ksplit, long P, int N,
+                                                              const float* __restrict__ bias,
+                                                              const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, float slope,
+                                                              float* y, long ldy, int accumulate) {
+  const long total4 = P * N / 4;
+  const long stride = P * N;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const long e = i * 4;
+    const long pix = e / N;
+    const int n = (int)(e - pix * N);
+    f32x4 s = *(const f32x4*)(slab + e);
+    for (int z = 1; z < ksplit; ++z) s += *(const f32x4*)(slab + z * stride + e);
+    float* dst = y + pix * ldy + n;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float v = s[k];
+      if (bias) v += bias[n + k];
+      if (scale) {
+        v = v * scale[n + k] + shift[n + k];
+        v = v > 0.f ? v : v * slope;
+      }
+      if (accumulate) v += dst[k];
+      s[k] = v;
+    }
+    *(f32x4*)dst = s;
+  }
+}
+
+// ---- host side ---------------------------------------------------------------------------------
+struct ConvPlan { int cfg; int BM, BN; int ksplit; long mtiles; int grid_y; };
+
+static ConvPlan plan_conv(int mode, long Mmax, int N, int nkt_min) {
+  ConvPlan pl{};
+  if (N % 128 == 0) {
+    if (Mmax <= 96) { pl.cfg = 4; pl.BM = 32; pl.BN = 128; }
+    else { pl.cfg = 0; pl.BM = 128; pl.BN = 128; }
+  } else if (N == 64) {
+    if (Mmax <= 512) { pl.cfg = 5; pl.BM = 64; pl.BN = 64; }
+    else { pl.cfg = 1; pl.BM = 128; pl.BN = 64; }
+  } else if (N == 32) { pl.cfg = 2; pl.BM = 256; pl.BN = 32; }
+  else { pl.cfg = 3; pl.BM = 256; pl.BN = 16; }
+  pl.mtiles = (Mmax + pl.BM - 1) / pl.BM;
+  pl.grid_y = (mode == MODE_PARITY) ? 4 : 1;
+  const long blocks = pl.mtiles * (N / pl.BN) * pl.grid_y;
+  int ks = 1;
+  if (blocks < 384) {
+    ks = (int)((768 + blocks - 1) / blocks);
+    const int cap = nkt_min / 8 > 1 ? nkt_min / 8 : 1;   // keep >= 8 K-tiles per split
+    if (ks > cap) ks = cap;
+    if (ks > 64) ks = 64;
+    if (ks < 1) ks = 1;
+  }
+  pl.ksplit = ks;
+  return pl;
+}
+
+template <int MODE>
+static int launch_conv_gemm(const ConvGemmArgs& a, const ConvPlan& pl, hipStream_t stream) {
+  dim3 grid((unsigned)(pl.mtiles * (a.N / pl.BN)), (unsigned)pl.grid_y, (unsigned)pl.ksplit);
+  dim3 block(256);
+  switch (pl.cfg) {
+    case 0: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 128, 128, 2, 2>), grid, block, 0, stream, a); break;
+    case 1: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 128, 64, 2, 2>), grid, block, 0, stream, a); break;
+    case 2: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 256, 32, 4, 1>), grid, block, 0, stream, a); break;
+    case 3: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 256, 16, 4, 1>), grid, block, 0, stream, a); break;
+    case 4: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 32, 128, 1, 4>), grid, block, 0, stream, a); break;
+    default: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 64, 64, 2, 2>), grid, block, 0, stream, a); break;
+  }
+  SVS_CHECK_LAUNCH("conv_gemm");
+  return SVS_OK;
+}
+
+static int check_gemm_args(const char* who, const float* x, long ldx, int B, int H, int W, int C, const float* wp,
+                           float* y, long ldy, int Ho, int Wo, int N) {
+  SVS_REQUIRE(x && wp && y, "%s: null pointer", who);
+  SVS_REQUIRE(B > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "%s: bad geometry B=%d H=%d W=%d", who, B, H, W);
+  SVS_REQUIRE(C >= 16 && C % 16 == 0, "%s: C=%d must be a multiple of 16", who, C);
+  SVS_REQUIRE(N >= 16 && (N == 16 || N == 32 || N == 64 || N % 128 == 0), "%s: unsupported N=%d", who, N);
+  SVS_REQUIRE(ldx >= C && ldx % 4 == 0 && ldy >= N && ldy % 4 == 0, "%s: bad ld (ldx=%ld ldy=%ld)", who, ldx, ldy);
+  SVS_REQUIRE(svs_aligned16(x) && svs_aligned16(wp) && svs_aligned16(y), "%s: pointers must be 16-byte aligned", who);
+  return SVS_OK;
+}
+
+// Shared by enc fwd / dec bwd_data (GATHER) and dec fwd / enc bwd_data (PARITY).
+int svs_conv_gemm_run(int mode, const float* x, long ldx, int B, int H, int W, int C, const float* wp,
+                      const float* bias, const float* scale, const float* shift, float slope, float* y, long ldy,
+                      int Ho, int Wo, int N, int accumulate, void* ws, size_t ws_bytes, hipStream_t stream,
+                      const char* who) {
+  int rc = check_gemm_args(who, x, ldx, B, H, W, C, wp, y, ldy, Ho, Wo, N);
+  if (rc) return rc;
+  long Mmax;
+  int nkt_min;
+  if (mode == MODE_GATHER) {
+    SVS_REQUIRE(Ho == svs_conv_out(H) && Wo == svs_conv_out(W), "%s: output %dx%d does not match input %dx%d", who, Ho, Wo, H, W);
+    Mmax = (long)B * Ho * Wo;
+    nkt_min = 25 * (C / 16);
+  } else {
+    SVS_REQUIRE((Ho == 2 * H || Ho == 2 * H - 1) && (Wo == 2 * W || Wo == 2 * W - 1),
+                "%s: output %dx%d unreachable from input %dx%d", who, Ho, Wo, H, W);
+    Mmax = (long)B * ((Ho + 1) / 2) * ((Wo + 1) / 2);
+    nkt_min = 4 * (C / 16);
+  }
+  ConvPlan pl = plan_conv(mode, Mmax, N, nkt_min);
+  ConvGemmArgs a{};
+  a.x = x; a.ldx = ldx; a.B = B; a.H = H; a.W = W; a.C = C; a.wp = wp;
+  a.bias = bias; a.scale = scale; a.shift = shift; a.slope = slope;
+  a.y = y; a.ldy = ldy; a.Ho = Ho; a.Wo = Wo; a.N = N; a.accumulate = accumulate;
+  a.ksplit = pl.ksplit; a.slab = nullptr;
+  const long P = (long)B * Ho * Wo;
+  if (pl.ksplit > 1) {
+    const size_t need = (size_t)pl.ksplit * P * N * sizeof(float);
+    if (!ws || ws_bytes < need || !svs_aligned16(ws)) {
+      svs_set_error("%s: workspace too small (%zu < %zu)", who, ws_bytes, need);
+      return SVS_ERR_WORKSPACE;
+    }
+    a.slab = (float*)ws;
+  }
+  rc = (mode == MODE_GATHER) ? launch_conv_gemm<MODE_GATHER>(a, pl, stream) : launch_conv_gemm<MODE_PARITY>(a, pl, stream);
+  if (rc) return rc;
+  if (pl.ksplit > 1) {
+    const long total4 = P * N / 4;
+    int grid = (int)((total4 + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(grid), dim3(256), 0, stream, a.slab, pl.ksplit, P, N, bias, scale,
+                       shift, slope, y, ldy, accumulate);
+    SVS_CHECK_LAUNCH("splitk_epilogue");
+  }
+  return SVS_OK;
+}
+
+size_t svs_conv_gemm_workspace(int mode, int B, int H, int W, int C, int Ho, int Wo, int N) {
+  if (C < 16 || N < 16) return 0;
+  long Mmax;
+  int nkt_min;
+  if (mode == MODE_GATHER) { Mmax = (long)B * Ho * Wo; nkt_min = 25 * (C / 16); }
+  else { Mmax = (long)B * ((Ho + 1) / 2) * ((Wo + 1) / 2); nkt_min = 4 * (C / 16); }
+  ConvPlan pl = plan_conv(mode, Mmax, N, nkt_min);
+  if (pl.ksplit <= 1) return 0;
+  return (size_t)pl.ksplit * B * Ho * Wo * N * sizeof(float);
+}

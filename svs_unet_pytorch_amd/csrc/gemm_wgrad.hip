@@ -1,0 +1,227 @@
+// Weight gradients of the 5x5 / stride-2 layers as an MFMA GEMM over pixels (fp32, 16x16x4), gfx950.
+//
+//   dw[cs][cl][kh][kw] = sum_{b,i,j} S[b,i,j,cs] * L[b,2i-2+kh,2j-2+kw,cl]
+//
+// S is the image on the strided (small) grid, L the one that is read through the 5x5 window:
+//   Conv2d          (model.py:48):  S = dy (N ch), L = x (C ch)   -> dw is (N,C,5,5)
+//   ConvTranspose2d (model.py:79):  S = x (C ch),  L = dy (N ch)  -> dw is (C,N,5,5)
+// so one kernel serves both.  GEMM view: M = cs, N = (tap, cl) with cl fastest (25*Cl columns),
+// K = pixels (b,i,j).  Both operands are contiguous along M resp. N in NHWC, so K-tiles of 16 pixels
+// are staged as As[k][m], Bs[k][n] (16-byte global loads / LDS stores) and the MFMA operands are
+// fetched with conflict-free ds_read_b32 (rows padded by 4 floats).  K is split over gridDim.z; each
+// split writes an fp32 slab and wgrad_reduce_kernel sums the slabs in a fixed order (bitwise
+// reproducible, no atomics) while transposing into torch's (cs,cl,kh,kw) layout.
+//
+// Bound: MFMA; algorithmic FLOPs = 2 * Cs * 25*Cl * B*Hs*Ws.
+#include "common.h"
+
+struct WgradArgs {
+  const float* s; long lds; int Hs, Ws, Cs;
+  const float* l; long ldl; int Hl, Wl, Cl;
+  int B;
+  float* slab;           // [ksplit][Cs][25*Cl]
+  long pix_per_split;    // multiple of 16
+};
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void wgrad_gemm_kernel(WgradArgs p) {
+  constexpr int TM = BM / WM / 16;
+  constexpr int TN = BN / WN / 16;
+  constexpr int LDA = BM + 4, LDB = BN + 4;
+  constexpr int CA = BM / 4, CB = BN / 4;            // 16-byte chunks per k-row
+  constexpr int RA = (16 * CA + 255) / 256, RB = (16 * CB + 255) / 256;
+  static_assert(WM * WN == 4, "4 waves");
+
+  __shared__ __attribute__((aligned(16))) float As[2][16 * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[2][16 * LDB];
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int lrow = lane & 15, q = lane >> 4;
+
+  const int Ntot = 25 * p.Cl;
+  const int cs0 = blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const long P = (long)p.B * p.Hs * p.Ws;
+  const long p_begin = (long)blockIdx.z * p.pix_per_split;
+  long p_end = p_begin + p.pix_per_split;
+  if (p_end > P) p_end = P;
+
+  // fixed (k-row, chunk) assignments
+  int ak[RA], ac[RA]; bool aok[RA];
+#pragma unroll
+  for (int r = 0; r < RA; ++r) {
+    const int idx = t + 256 * r;
+    ak[r] = idx / CA; ac[r] = idx % CA; aok[r] = idx < 16 * CA;
+  }
+  int bk[RB], bc[RB], bkh[RB], bkw[RB], bcl[RB]; bool bok[RB];
+#pragma unroll
+  for (int r = 0; r < RB; ++r) {
+    const int idx = t + 256 * r;
+    bk[r] = idx / CB; bc[r] = idx % CB;
+    const int n = n0 + bc[r] * 4;
+    bok[r] = (idx < 16 * CB) && (n < Ntot);
+    const int tap = bok[r] ? n / p.Cl : 0;
+    bcl[r] = bok[r] ? n - tap * p.Cl : 0;
+    bkh[r] = tap / 5; bkw[r] = tap - bkh[r] * 5;
+  }
+
+  f32x4 ra[RA], rb[RB];
+  auto load_tile = [&](long pk) {
+#pragma unroll
+    for (int r = 0; r < RA; ++r) {
+      const long pix = pk + ak[r];
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (aok[r] && pix < p_end) v = *(const f32x4*)(p.s + pix * p.lds + cs0 + ac[r] * 4);
+      ra[r] = v;
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const long pix = pk + bk[r];
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (bok[r] && pix < p_end) {
+        const int j = (int)(pix % p.Ws);
+        const long tmp = pix / p.Ws;
+        const int i = (int)(tmp % p.Hs);
+        const long b = tmp / p.Hs;
+        const int ih = 2 * i - 2 + bkh[r], iw = 2 * j - 2 + bkw[r];
+        if ((unsigned)ih < (unsigned)p.Hl && (unsigned)iw < (unsigned)p.Wl)
+          v = *(const f32x4*)(p.l + ((b * p.Hl + ih) * p.Wl + iw) * p.ldl + bcl[r]);
+      }
+      rb[r] = v;
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int r = 0; r < RA; ++r)
+      if (aok[r]) *(f32x4*)(&As[buf][ak[r] * LDA + ac[r] * 4]) = ra[r];
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+      if (t + 256 * r < 16 * CB) *(f32x4*)(&Bs[buf][bk[r] * LDB + bc[r] * 4]) = rb[r];
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (p_begin < p_end) {
+    load_tile(p_begin);
+    store_tile(0);
+  }
+  __syncthreads();
+  int it = 0;
+  for (long pk = p_begin; pk < p_end; pk += 16, ++it) {
+    const int buf = it & 1;
+    const bool more = pk + 16 < p_end;
+    if (more) load_tile(pk + 16);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float fa[TM], fb[TN];
+      const int kr = 4 * q + k;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = As[buf][kr * LDA + wm * (TM * 16) + i * 16 + lrow];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j] = Bs[buf][kr * LDB + wn * (TN * 16) + j * 16 + lrow];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  float* slab = p.slab + (long)blockIdx.z * p.Cs * Ntot;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int cs = cs0 + wm * (TM * 16) + i * 16 + q * 4 + r;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (TN * 16) + j * 16 + lrow;
+        if (n < Ntot) slab[(long)cs * Ntot + n] = acc[i][j][r];
+      }
+    }
+}
+
+// dw[(cs*Cl + cl)*25 + tap] = sum_z slab[z][cs][tap*Cl + cl]
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int ksplit, int Cs, int Cl,
+                                                           float* __restrict__ dw) {
+  const long total = (long)Cs * Cl * 25;
+  const long zstride = total;
+  for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+    const int tap = (int)(o % 25);
+    const long cc = o / 25;
+    const int cl = (int)(cc % Cl);
+    const long cs = cc / Cl;
+    const long src = cs * (25L * Cl) + (long)tap * Cl + cl;
+    float s = 0.f;
+    for (int z = 0; z < ksplit; ++z) s += slab[z * zstride + src];
+    dw[o] = s;
+  }
+}
+
+struct WgradPlan { int cfg, BM, BN, ksplit; long pps; };
+
+static WgradPlan plan_wgrad(int B, int Hs, int Ws, int Cs, int Cl) {
+  WgradPlan pl{};
+  if (Cs % 128 == 0) { pl.cfg = 0; pl.BM = 128; }
+  else if (Cs % 64 == 0) { pl.cfg = 1; pl.BM = 64; }
+  else { pl.cfg = 2; pl.BM = 32; }
+  pl.BN = 128;
+  const long P = (long)B * Hs * Ws;
+  const long blocks_mn = (long)(Cs / pl.BM) * ((25L * Cl + pl.BN - 1) / pl.BN);
+  long ks = (1024 + blocks_mn - 1) / blocks_mn;
+  const long cap = P / 128 > 1 ? P / 128 : 1;      // >= 8 K-tiles per split
+  if (ks > cap) ks = cap;
+  if (ks > 512) ks = 512;
+  if (ks < 1) ks = 1;
+  long pps = (P + ks - 1) / ks;
+  pps = (pps + 15) / 16 * 16;
+  ks = (P + pps - 1) / pps;
+  pl.ksplit = (int)ks;
+  pl.pps = pps;
+  return pl;
+}
+
+size_t svs_wgrad_gemm_workspace(int B, int Hs, int Ws, int Cs, int Cl) {
+  WgradPlan pl = plan_wgrad(B, Hs, Ws, Cs, Cl);
+  return (size_t)pl.ksplit * Cs * 25 * Cl * sizeof(float);
+}
+
+int svs_wgrad_gemm_run(const float* s, long lds, int B, int Hs, int Ws, int Cs, const float* l, long ldl, int Hl,
+                       int Wl, int Cl, float* dw, void* ws, size_t ws_bytes, hipStream_t stream, const char* who) {
+  SVS_REQUIRE(s && l && dw, "%s: null pointer", who);
+  SVS_REQUIRE(Cs >= 32 && Cs % 32 == 0 && Cl >= 16 && Cl % 4 == 0, "%s: unsupported channels Cs=%d Cl=%d", who, Cs, Cl);
+  SVS_REQUIRE(Hs == svs_conv_out(Hl) && Ws == svs_conv_out(Wl), "%s: small grid %dx%d does not match %dx%d", who, Hs, Ws, Hl, Wl);
+  SVS_REQUIRE(lds >= Cs && lds % 4 == 0 && ldl >= Cl && ldl % 4 == 0, "%s: bad ld", who);
+  SVS_REQUIRE(svs_aligned16(s) && svs_aligned16(l) && svs_aligned16(ws), "%s: pointers must be 16-byte aligned", who);
+  WgradPlan pl = plan_wgrad(B, Hs, Ws, Cs, Cl);
+  const size_t need = (size_t)pl.ksplit * Cs * 25 * Cl * sizeof(float);
+  if (!ws || ws_bytes < need) {
+    svs_set_error("%s: workspace too small (%zu < %zu)", who, ws_bytes, need);
+    return SVS_ERR_WORKSPACE;
+  }
+  WgradArgs a{};
+  a.s = s; a.lds = lds; a.Hs = Hs; a.Ws = Ws; a.Cs = Cs;
+  a.l = l; a.ldl = ldl; a.Hl = Hl; a.Wl = Wl; a.Cl = Cl;
+  a.B = B; a.slab = (float*)ws; a.pix_per_split = pl.pps;
+  dim3 grid((unsigned)(Cs / pl.BM), (unsigned)((25 * Cl + pl.BN - 1) / pl.BN), (unsigned)pl.ksplit);
+  switch (pl.cfg) {
+    case 0: hipLaunchKernelGGL((wgrad_gemm_kernel<128, 128, 2, 2>), grid, dim3(256), 0, stream, a); break;
+    case 1: hipLaunchKernelGGL((wgrad_gemm_kernel<64, 128, 1, 4>), grid, dim3(256), 0, stream, a); break;
+    default: hipLaunchKernelGGL((wgrad_gemm_kernel<32, 128, 1, 4>), grid, dim3(256), 0, stream, a); break;
+  }
+  SVS_CHECK_LAUNCH("wgrad_gemm");
+  const long total = (long)Cs * Cl * 25;
+  int rg = (int)((total + 255) / 256);
+  if (rg > 4096) rg = 4096;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rg), dim3(256), 0, stream, (const float*)ws, pl.ksplit, Cs, Cl, dw);
+  SVS_CHECK_LAUNCH("wgrad_reduce");
+  return SVS_OK;
+}

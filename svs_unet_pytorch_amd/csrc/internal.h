@@ -1,0 +1,28 @@
+// Internal (non-exported) launchers shared between translation units of libsvs_hip.so.
+#pragma once
+#include "common.h"
+
+enum { SVS_MODE_GATHER = 0, SVS_MODE_PARITY = 1 };
+
+int svs_conv_gemm_run(int mode, const float* x, long ldx, int B, int H, int W, int C, const float* wp,
+                      const float* bias, const float* scale, const float* shift, float slope, float* y, long ldy,
+                      int Ho, int Wo, int N, int accumulate, void* ws, size_t ws_bytes, hipStream_t stream,
+                      const char* who);
+size_t svs_conv_gemm_workspace(int mode, int B, int H, int W, int C, int Ho, int Wo, int N);
+
+int svs_wgrad_gemm_run(const float* s, long lds, int B, int Hs, int Ws, int Cs, const float* l, long ldl, int Hl,
+                       int Wl, int Cl, float* dw, void* ws, size_t ws_bytes, hipStream_t stream, const char* who);
+size_t svs_wgrad_gemm_workspace(int B, int Hs, int Ws, int Cs, int Cl);
+
+int svs_conv_c1_run(const float* x, int B, int H, int W, const float* w, const float* bias, const float* scale,
+                    const float* shift, float slope, float* y, long ldy, int N, int accumulate, hipStream_t stream,
+                    const char* who);
+int svs_deconv_to1_run(const float* x, long ldx, int B, int H, int W, int C, const float* w, const float* bias,
+                       float* y, int Ho, int Wo, int apply_sigmoid, hipStream_t stream, const char* who);
+int svs_wgrad_c1_run(const float* s, long lds, int B, int Hs, int Ws, int Cs, const float* l, int Hl, int Wl,
+                     float* dw, void* ws, size_t ws_bytes, hipStream_t stream, const char* who);
+size_t svs_wgrad_c1_workspace(int B, int Hs, int Ws, int Cs);
+
+int svs_channel_sum_run(const float* x, long ldx, long P, int C, float* out, void* ws, size_t ws_bytes, hipStream_t stream);
+int svs_sum_run(const float* x, long n, float* out, void* ws, size_t ws_bytes, hipStream_t stream);
+int svs_sigmoid_bwd_run(const float* mask, const float* dmask, long n, float* d_logit, hipStream_t stream);

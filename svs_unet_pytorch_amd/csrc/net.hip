@@ -1,0 +1,511 @@
+// Host-side orchestration of the U-Net on one GPU: the per-block C-ABI wrappers and the whole-network
+// eval forward / training forward+backward (one C call per step; every kernel goes to the caller's
+// stream, nothing synchronises, so the calls are hipGraph-capturable).
+//
+// HBM layout (fp32, NHWC).  Level k (k = 0..6) has spatial size (h[k], w[k]) = repeated ceil-halving
+// of the input and ch[k] = {1,16,32,64,128,256,512} channels (reference model.py:47-76).
+//   cat[k], k=1..5 : (B, h[k], w[k], 2*ch[k])   first half  = output of decoder 6-k  (model.py:183-196)
+//                                                second half = output of encoder k    (model.py:176-180)
+//                    -> torch.cat([deconv_out, conv_out], 1) of model.py:186-198 is never materialised:
+//                       producers write their half with ld = 2*ch[k], consumers read the full width.
+//   c6             : (B, h[6], w[6], 512)
+// Training additionally keeps the pre-BatchNorm ("raw") output of every block, the batch statistics,
+// both weight packings, and gradient images dcat[k] / dc6 of the same shapes.
+#include <math.h>
+#include <stdarg.h>
+#include <string.h>
+
+#include "internal.h"
+
+// ---------------------------------------------------------------------------------------------
+// error string
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void svs_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* svs_last_error_string(void) { return g_err; }
+extern "C" int svs_version(void) { return SVS_ABI_VERSION; }
+
+// ---------------------------------------------------------------------------------------------
+// per-block wrappers
+// ---------------------------------------------------------------------------------------------
+extern "C" size_t svs_enc_block_workspace_bytes(int B, int H, int W, int C, int N) {
+  return svs_conv_gemm_workspace(SVS_MODE_GATHER, B, H, W, C, svs_conv_out(H), svs_conv_out(W), N);
+}
+extern "C" int svs_enc_block_fwd(const float* x, int64_t ldx, int B, int H, int W, int C, const float* wp,
+                                 const float* bias, const float* scale, const float* shift, float slope, float* y,
+                                 int64_t ldy, int N, int accumulate, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (C == 1) {
+    SVS_REQUIRE(ldx == 1, "svs_enc_block_fwd: single-channel input must be dense (ldx=1)");
+    return svs_conv_c1_run(x, B, H, W, wp, bias, scale, shift, slope, y, ldy, N, accumulate, stream, "svs_enc_block_fwd");
+  }
+  return svs_conv_gemm_run(SVS_MODE_GATHER, x, ldx, B, H, W, C, wp, bias, scale, shift, slope, y, ldy, svs_conv_out(H),
+                           svs_conv_out(W), N, accumulate, ws, ws_bytes, stream, "svs_enc_block_fwd");
+}
+extern "C" size_t svs_dec_block_workspace_bytes(int B, int H, int W, int C, int Ho, int Wo, int N) {
+  return svs_conv_gemm_workspace(SVS_MODE_PARITY, B, H, W, C, Ho, Wo, N);
+}
+extern "C" int svs_dec_block_fwd(const float* x, int64_t ldx, int B, int H, int W, int C, const float* wp,
+                                 const float* bias, const float* scale, const float* shift, float slope, float* y,
+                                 int64_t ldy, int Ho, int Wo, int N, int accumulate, void* ws, size_t ws_bytes,
+                                 hipStream_t stream) {
+  return svs_conv_gemm_run(SVS_MODE_PARITY, x, ldx, B, H, W, C, wp, bias, scale, shift, slope, y, ldy, Ho, Wo, N,
+                           accumulate, ws, ws_bytes, stream, "svs_dec_block_fwd");
+}
+extern "C" int svs_out_block_fwd(const float* x, int64_t ldx, int B, int H, int W, int C, const float* w,
+                                 const float* bias, float* y, int Ho, int Wo, int apply_sigmoid, hipStream_t stream) {
+  return svs_deconv_to1_run(x, ldx, B, H, W, C, w, bias, y, Ho, Wo, apply_sigmoid, stream, "svs_out_block_fwd");
+}
+extern "C" int svs_enc_block_bwd_data(const float* dy, int64_t lddy, int B, int Ho, int Wo, int N, const float* wpar,
+                                      float* dx, int64_t lddx, int H, int W, int C, int accumulate, void* ws,
+                                      size_t ws_bytes, hipStream_t stream) {
+  // transposed conv of dy: "input" is (Ho,Wo,N), "output" is (H,W,C)
+  return svs_conv_gemm_run(SVS_MODE_PARITY, dy, lddy, B, Ho, Wo, N, wpar, nullptr, nullptr, nullptr, 0.f, dx, lddx, H, W,
+                           C, accumulate, ws, ws_bytes, stream, "svs_enc_block_bwd_data");
+}
+extern "C" int svs_dec_block_bwd_data(const float* dy, int64_t lddy, int B, int Ho, int Wo, int N, const float* wgat,
+                                      float* dx, int64_t lddx, int H, int W, int C, int accumulate, void* ws,
+                                      size_t ws_bytes, hipStream_t stream) {
+  // strided conv of dy: "input" is (Ho,Wo,N), "output" is (H,W,C) with H = ceil(Ho/2)
+  if (N == 1) {
+    SVS_REQUIRE(lddy == 1, "svs_dec_block_bwd_data: single-channel gradient must be dense");
+    SVS_REQUIRE(H == svs_conv_out(Ho) && W == svs_conv_out(Wo), "svs_dec_block_bwd_data: geometry mismatch");
+    return svs_conv_c1_run(dy, B, Ho, Wo, wgat, nullptr, nullptr, nullptr, 0.f, dx, lddx, C, accumulate, stream,
+                           "svs_dec_block_bwd_data");
+  }
+  return svs_conv_gemm_run(SVS_MODE_GATHER, dy, lddy, B, Ho, Wo, N, wgat, nullptr, nullptr, nullptr, 0.f, dx, lddx, H, W,
+                           C, accumulate, ws, ws_bytes, stream, "svs_dec_block_bwd_data");
+}
+extern "C" size_t svs_block_bwd_weight_workspace_bytes(int B, int Hs, int Ws, int Cs, int Cl) {
+  size_t a = (Cl == 1) ? svs_wgrad_c1_workspace(B, Hs, Ws, Cs) : svs_wgrad_gemm_workspace(B, Hs, Ws, Cs, Cl);
+  size_t b = svs_bn_workspace_bytes((int64_t)B * Hs * Ws * 4, Cs > Cl ? Cs : Cl);   // bias-gradient partials
+  return a > b ? a : b;
+}
+extern "C" int svs_enc_block_bwd_weight(const float* dy, int64_t lddy, int B, int Ho, int Wo, int N, const float* x,
+                                        int64_t ldx, int H, int W, int C, float* dw, float* db, void* ws,
+                                        size_t ws_bytes, hipStream_t stream) {
+  int rc;
+  if (C == 1) rc = svs_wgrad_c1_run(dy, lddy, B, Ho, Wo, N, x, H, W, dw, ws, ws_bytes, stream, "svs_enc_block_bwd_weight");
+  else rc = svs_wgrad_gemm_run(dy, lddy, B, Ho, Wo, N, x, ldx, H, W, C, dw, ws, ws_bytes, stream, "svs_enc_block_bwd_weight");
+  if (rc || !db) return rc;
+  return svs_channel_sum_run(dy, lddy, (long)B * Ho * Wo, N, db, ws, ws_bytes, stream);
+}
+extern "C" int svs_dec_block_bwd_weight(const float* x, int64_t ldx, int B, int H, int W, int C, const float* dy,
+                                        int64_t lddy, int Ho, int Wo, int N, float* dw, float* db, void* ws,
+                                        size_t ws_bytes, hipStream_t stream) {
+  int rc;
+  if (N == 1) {
+    rc = svs_wgrad_c1_run(x, ldx, B, H, W, C, dy, Ho, Wo, dw, ws, ws_bytes, stream, "svs_dec_block_bwd_weight");
+    if (rc || !db) return rc;
+    return svs_sum_run(dy, (long)B * Ho * Wo, db, ws, ws_bytes, stream);
+  }
+  rc = svs_wgrad_gemm_run(x, ldx, B, H, W, C, dy, lddy, Ho, Wo, N, dw, ws, ws_bytes, stream, "svs_dec_block_bwd_weight");
+  if (rc || !db) return rc;
+  return svs_channel_sum_run(dy, lddy, (long)B * Ho * Wo, N, db, ws, ws_bytes, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// network description
+// ---------------------------------------------------------------------------------------------
+static const int CH[7] = {1, 16, 32, 64, 128, 256, 512};                 // model.py:47-76
+static const int DEC_C[6] = {512, 512, 256, 128, 64, 32};                // model.py:79-109 (in)
+static const int DEC_N[6] = {256, 128, 64, 32, 16, 1};                   //                 (out)
+#define BN_EPS 1e-5f
+#define BN_MOMENTUM 0.1f
+#define LEAKY 0.2f
+
+// parameter tensor index: enc k (1..6): 4*(k-1) + {0 w, 1 b, 2 gamma, 3 beta}; dec j (1..6): 24 + 4*(j-1) + {...}
+static long param_numel(int idx) {
+  if (idx < 24) {
+    const int k = idx / 4 + 1, f = idx % 4;
+    return f == 0 ? (long)CH[k] * CH[k - 1] * 25 : CH[k];
+  }
+  const int j = (idx - 24) / 4, f = (idx - 24) % 4;
+  return f == 0 ? (long)DEC_C[j] * DEC_N[j] * 25 : DEC_N[j];
+}
+extern "C" int64_t svs_unet_param_offset(int tensor_index) {
+  if (tensor_index < 0 || tensor_index > SVS_UNET_NUM_PARAMS) return -1;
+  long off = 0;
+  for (int i = 0; i < tensor_index; ++i) off += param_numel(i);
+  return off;
+}
+static int bn_channels(int bn) { return bn < 6 ? CH[bn + 1] : DEC_N[bn - 6]; }
+extern "C" int64_t svs_unet_buffer_offset(int bn_index, int which) {
+  if (bn_index < 0 || bn_index > SVS_UNET_NUM_BN) return -1;
+  long off = 0;
+  for (int i = 0; i < bn_index; ++i) off += 2 * bn_channels(i);
+  if (bn_index < SVS_UNET_NUM_BN && which) off += bn_channels(bn_index);
+  return off;
+}
+
+struct ParamView {
+  const float* w[12]; const float* b[12]; const float* gamma[11]; const float* beta[11];   // 0..5 enc, 6..11 dec
+};
+static ParamView view_params(const float* params) {
+  ParamView v{};
+  for (int l = 0; l < 12; ++l) {
+    const int base = 4 * l;
+    v.w[l] = params + svs_unet_param_offset(base);
+    v.b[l] = params + svs_unet_param_offset(base + 1);
+    if (l < 11) {
+      v.gamma[l] = params + svs_unet_param_offset(base + 2);
+      v.beta[l] = params + svs_unet_param_offset(base + 3);
+    }
+  }
+  return v;
+}
+
+struct Geo { int B; int h[7], w[7]; long P[7]; };
+static int make_geo(int B, int H, int W, Geo& g) {
+  SVS_REQUIRE(B > 0 && H > 0 && W > 0, "bad tile geometry B=%d H=%d W=%d", B, H, W);
+  g.B = B; g.h[0] = H; g.w[0] = W;
+  for (int k = 1; k <= 6; ++k) { g.h[k] = svs_conv_out(g.h[k - 1]); g.w[k] = svs_conv_out(g.w[k - 1]); }
+  for (int k = 0; k <= 6; ++k) g.P[k] = (long)B * g.h[k] * g.w[k];
+  return SVS_OK;
+}
+
+// bump allocator over the caller's workspace (every block 256-byte aligned)
+struct Arena {
+  char* base; size_t used;
+  float* take(size_t nfloats) {
+    float* p = base ? (float*)(base + used) : nullptr;
+    used += svs_align_up(nfloats * sizeof(float), 256);
+    return p;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// eval
+// ---------------------------------------------------------------------------------------------
+struct Prepared {      // offsets in floats into the prepared blob
+  long wp[12], scale[11], shift[11], bias6, total;
+};
+static Prepared prepared_layout() {
+  Prepared p{};
+  long off = 0;
+  auto take = [&](long n) { long o = off; off += (n + 63) / 64 * 64; return o; };
+  for (int l = 0; l < 12; ++l) p.wp[l] = take(param_numel(4 * l));
+  for (int l = 0; l < 11; ++l) { p.scale[l] = take(bn_channels(l)); p.shift[l] = take(bn_channels(l)); }
+  p.bias6 = take(1);
+  p.total = off;
+  return p;
+}
+extern "C" size_t svs_unet_prepared_bytes(void) { return (size_t)prepared_layout().total * sizeof(float); }
+
+extern "C" int svs_unet_prepare_eval(const float* params, const float* bn_buffers, void* prepared, hipStream_t stream) {
+  SVS_REQUIRE(params && bn_buffers && prepared && svs_aligned16(params) && svs_aligned16(prepared), "svs_unet_prepare_eval: bad pointers");
+  const Prepared L = prepared_layout();
+  const ParamView v = view_params(params);
+  float* blob = (float*)prepared;
+  int rc;
+  // conv1: C == 1, the gather packing is torch's layout; deconv6: N == 1, kernel reads torch's layout
+  SVS_HIP(hipMemcpyAsync(blob + L.wp[0], v.w[0], param_numel(0) * sizeof(float), hipMemcpyDeviceToDevice, stream));
+  for (int k = 2; k <= 6; ++k)
+    if ((rc = svs_pack_weight_gather(v.w[k - 1], blob + L.wp[k - 1], CH[k], CH[k - 1], stream))) return rc;
+  for (int j = 0; j < 5; ++j)
+    if ((rc = svs_pack_weight_parity(v.w[6 + j], blob + L.wp[6 + j], DEC_C[j], DEC_N[j], stream))) return rc;
+  SVS_HIP(hipMemcpyAsync(blob + L.wp[11], v.w[11], param_numel(44) * sizeof(float), hipMemcpyDeviceToDevice, stream));
+  SVS_HIP(hipMemcpyAsync(blob + L.bias6, v.b[11], sizeof(float), hipMemcpyDeviceToDevice, stream));
+  for (int l = 0; l < 11; ++l) {
+    const float* rm = bn_buffers + svs_unet_buffer_offset(l, 0);
+    const float* rv = bn_buffers + svs_unet_buffer_offset(l, 1);
+    if ((rc = svs_bn_fold(v.gamma[l], v.beta[l], rm, rv, v.b[l], BN_EPS, blob + L.scale[l], blob + L.shift[l], bn_channels(l), stream))) return rc;
+  }
+  return SVS_OK;
+}
+
+struct EvalWs { float* cat[6]; float* c6; float* scratch; size_t scratch_bytes; size_t total; };
+static EvalWs eval_layout(const Geo& g, void* ws) {
+  EvalWs e{};
+  Arena a{(char*)ws, 0};
+  for (int k = 1; k <= 5; ++k) e.cat[k] = a.take((size_t)g.P[k] * 2 * CH[k]);
+  e.c6 = a.take((size_t)g.P[6] * 512);
+  size_t sb = 0;
+  for (int k = 2; k <= 6; ++k) {
+    size_t s = svs_conv_gemm_workspace(SVS_MODE_GATHER, g.B, g.h[k - 1], g.w[k - 1], CH[k - 1], g.h[k], g.w[k], CH[k]);
+    if (s > sb) sb = s;
+  }
+  for (int j = 0; j < 5; ++j) {
+    size_t s = svs_conv_gemm_workspace(SVS_MODE_PARITY, g.B, g.h[6 - j], g.w[6 - j], DEC_C[j], g.h[5 - j], g.w[5 - j], DEC_N[j]);
+    if (s > sb) sb = s;
+  }
+  e.scratch_bytes = sb;
+  e.scratch = a.take(sb / sizeof(float) + 64);
+  e.total = a.used;
+  return e;
+}
+extern "C" size_t svs_unet_eval_workspace_bytes(int B, int H, int W) {
+  Geo g;
+  if (make_geo(B, H, W, g)) return 0;
+  return eval_layout(g, nullptr).total;
+}
+
+extern "C" int svs_unet_forward_eval(const void* prepared, const float* mix, float* mask, int B, int H, int W, void* ws,
+                                     size_t ws_bytes, hipStream_t stream) {
+  Geo g;
+  int rc = make_geo(B, H, W, g);
+  if (rc) return rc;
+  SVS_REQUIRE(prepared && mix && mask && svs_aligned16(mix) && svs_aligned16(mask), "svs_unet_forward_eval: bad pointers");
+  const EvalWs e = eval_layout(g, ws);
+  if (!ws || ws_bytes < e.total || !svs_aligned16(ws)) { svs_set_error("svs_unet_forward_eval: workspace too small (%zu < %zu)", ws_bytes, e.total); return SVS_ERR_WORKSPACE; }
+  const Prepared L = prepared_layout();
+  const float* blob = (const float*)prepared;
+  // encoder (model.py:176-181): BN folded, LeakyReLU(0.2) in the epilogue
+  for (int k = 1; k <= 6; ++k) {
+    const float* x = (k == 1) ? mix : e.cat[k - 1] + CH[k - 1];
+    const long ldx = (k == 1) ? 1 : 2 * CH[k - 1];
+    float* y = (k == 6) ? e.c6 : e.cat[k] + CH[k];
+    const long ldy = (k == 6) ? 512 : 2 * CH[k];
+    rc = svs_enc_block_fwd(x, ldx, B, g.h[k - 1], g.w[k - 1], CH[k - 1], blob + L.wp[k - 1], nullptr,
+                           blob + L.scale[k - 1], blob + L.shift[k - 1], LEAKY, y, ldy, CH[k], 0, e.scratch, e.scratch_bytes, stream);
+    if (rc) return rc;
+  }
+  // decoder (model.py:183-196): BN folded, ReLU; Dropout2d is the identity in eval
+  for (int j = 0; j < 5; ++j) {
+    const int lin = 6 - j, lout = 5 - j;
+    const float* x = (j == 0) ? e.c6 : e.cat[lin];
+    rc = svs_dec_block_fwd(x, DEC_C[j], B, g.h[lin], g.w[lin], DEC_C[j], blob + L.wp[6 + j], nullptr, blob + L.scale[6 + j],
+                           blob + L.shift[6 + j], 0.f, e.cat[lout], 2 * CH[lout], g.h[lout], g.w[lout], DEC_N[j], 0,
+                           e.scratch, e.scratch_bytes, stream);
+    if (rc) return rc;
+  }
+  // deconv6 + sigmoid (model.py:198-200)
+  return svs_out_block_fwd(e.cat[1], 32, B, g.h[1], g.w[1], 32, blob + L.wp[11], blob + L.bias6, mask, H, W, 1, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// training
+// ---------------------------------------------------------------------------------------------
+struct TrainWs {
+  float* cat[6]; float* c6;
+  float* raw_e[7]; float* raw_d[5];
+  float* mean[11]; float* invstd[11];
+  float* wfwd[12]; float* wbwd[12];       // packed weights (null where torch's layout is read directly)
+  float* dcat[6]; float* dc6;
+  float* d_raw; float* d_logit; float* mask;
+  float* bnws; size_t bnws_bytes;
+  float* scratch; size_t scratch_bytes;
+  size_t total;
+};
+static TrainWs train_layout(const Geo& g, void* ws) {
+  TrainWs t{};
+  Arena a{(char*)ws, 0};
+  const int B = g.B;
+  for (int k = 1; k <= 5; ++k) t.cat[k] = a.take((size_t)g.P[k] * 2 * CH[k]);
+  t.c6 = a.take((size_t)g.P[6] * 512);
+  for (int k = 1; k <= 6; ++k) t.raw_e[k] = a.take((size_t)g.P[k] * CH[k]);
+  for (int j = 0; j < 5; ++j) t.raw_d[j] = a.take((size_t)g.P[5 - j] * DEC_N[j]);
+  for (int l = 0; l < 11; ++l) { t.mean[l] = a.take(bn_channels(l)); t.invstd[l] = a.take(bn_channels(l)); }
+  for (int k = 2; k <= 6; ++k) { t.wfwd[k - 1] = a.take(param_numel(4 * (k - 1))); t.wbwd[k - 1] = a.take(param_numel(4 * (k - 1))); }
+  for (int j = 0; j < 5; ++j) { t.wfwd[6 + j] = a.take(param_numel(24 + 4 * j)); t.wbwd[6 + j] = a.take(param_numel(24 + 4 * j)); }
+  for (int k = 1; k <= 5; ++k) t.dcat[k] = a.take((size_t)g.P[k] * 2 * CH[k]);
+  t.dc6 = a.take((size_t)g.P[6] * 512);
+  size_t dmax = 0;
+  for (int k = 1; k <= 6; ++k) if ((size_t)g.P[k] * CH[k] > dmax) dmax = (size_t)g.P[k] * CH[k];
+  t.d_raw = a.take(dmax);
+  t.d_logit = a.take((size_t)g.P[0]);
+  t.mask = a.take((size_t)g.P[0]);
+  size_t bb = 0;
+  for (int k = 1; k <= 6; ++k) { size_t s = svs_bn_workspace_bytes(g.P[k], CH[k]); if (s > bb) bb = s; }
+  t.bnws_bytes = bb + 4096;
+  t.bnws = a.take(t.bnws_bytes / sizeof(float));
+  size_t sb = 4096;
+  auto upd = [&](size_t s) { if (s > sb) sb = s; };
+  for (int k = 2; k <= 6; ++k) {
+    upd(svs_conv_gemm_workspace(SVS_MODE_GATHER, B, g.h[k - 1], g.w[k - 1], CH[k - 1], g.h[k], g.w[k], CH[k]));
+    upd(svs_conv_gemm_workspace(SVS_MODE_PARITY, B, g.h[k], g.w[k], CH[k], g.h[k - 1], g.w[k - 1], CH[k - 1]));   // bwd data
+    upd(svs_block_bwd_weight_workspace_bytes(B, g.h[k], g.w[k], CH[k], CH[k - 1]));
+  }
+  upd(svs_block_bwd_weight_workspace_bytes(B, g.h[1], g.w[1], 16, 1));
+  for (int j = 0; j < 6; ++j) {
+    const int lin = 6 - j, lout = 5 - j;
+    if (j < 5) {
+      upd(svs_conv_gemm_workspace(SVS_MODE_PARITY, B, g.h[lin], g.w[lin], DEC_C[j], g.h[lout], g.w[lout], DEC_N[j]));
+      upd(svs_conv_gemm_workspace(SVS_MODE_GATHER, B, g.h[lout], g.w[lout], DEC_N[j], g.h[lin], g.w[lin], DEC_C[j]));  // bwd data
+    }
+    upd(svs_block_bwd_weight_workspace_bytes(B, g.h[lin], g.w[lin], DEC_C[j], DEC_N[j]));
+  }
+  t.scratch_bytes = sb;
+  t.scratch = a.take(sb / sizeof(float) + 64);
+  t.total = a.used;
+  return t;
+}
+extern "C" size_t svs_unet_train_workspace_bytes(int B, int H, int W) {
+  Geo g;
+  if (make_geo(B, H, W, g)) return 0;
+  return train_layout(g, nullptr).total;
+}
+
+extern "C" int64_t svs_unet_ws_offset(const char* name, int B, int H, int W, int training) {
+  Geo g;
+  if (!name || make_geo(B, H, W, g)) return -1;
+  char* const base = (char*)256;   // non-null dummy so the arena hands out addresses
+  auto rel = [&](const float* p) { return p ? (int64_t)((const char*)p - base) : (int64_t)-1; };
+  int idx = 0;
+  if (training) {
+    const TrainWs t = train_layout(g, base);
+    if (sscanf(name, "cat%d", &idx) == 1 && idx >= 1 && idx <= 5 && name[0] == 'c') return rel(t.cat[idx]);
+    if (!strcmp(name, "c6")) return rel(t.c6);
+    if (sscanf(name, "raw_e%d", &idx) == 1 && idx >= 1 && idx <= 6) return rel(t.raw_e[idx]);
+    if (sscanf(name, "raw_d%d", &idx) == 1 && idx >= 1 && idx <= 5) return rel(t.raw_d[idx - 1]);
+    if (sscanf(name, "dcat%d", &idx) == 1 && idx >= 1 && idx <= 5) return rel(t.dcat[idx]);
+    if (!strcmp(name, "dc6")) return rel(t.dc6);
+    if (!strcmp(name, "d_logit")) return rel(t.d_logit);
+    if (!strcmp(name, "mask")) return rel(t.mask);
+    if (sscanf(name, "mean%d", &idx) == 1 && idx >= 0 && idx < 11) return rel(t.mean[idx]);
+    if (sscanf(name, "invstd%d", &idx) == 1 && idx >= 0 && idx < 11) return rel(t.invstd[idx]);
+    return -1;
+  }
+  const EvalWs e = eval_layout(g, base);
+  if (sscanf(name, "cat%d", &idx) == 1 && idx >= 1 && idx <= 5) return rel(e.cat[idx]);
+  if (!strcmp(name, "c6")) return rel(e.c6);
+  return -1;
+}
+
+static int train_forward_impl(const ParamView& v, float* bn_buffers, int64_t* nbt, const float* mix, const float* drop,
+                              const Geo& g, const TrainWs& t, float* mask, hipStream_t stream) {
+  const int B = g.B;
+  int rc;
+  // weight packings for this step (weights change every optimiser step)
+  for (int k = 2; k <= 6; ++k) {
+    if ((rc = svs_pack_weight_gather(v.w[k - 1], t.wfwd[k - 1], CH[k], CH[k - 1], stream))) return rc;
+    if ((rc = svs_pack_weight_parity(v.w[k - 1], t.wbwd[k - 1], CH[k], CH[k - 1], stream))) return rc;   // conv (N,C,..) read as (in=N,out=C)
+  }
+  for (int j = 0; j < 5; ++j) {
+    if ((rc = svs_pack_weight_parity(v.w[6 + j], t.wfwd[6 + j], DEC_C[j], DEC_N[j], stream))) return rc;
+    if ((rc = svs_pack_weight_gather(v.w[6 + j], t.wbwd[6 + j], DEC_C[j], DEC_N[j], stream))) return rc;  // convT (C,N,..) read as (n=C,c=N)
+  }
+  // encoder: conv (+bias) -> raw; batch stats; BN + LeakyReLU -> second half of cat[k]
+  for (int k = 1; k <= 6; ++k) {
+    const float* x = (k == 1) ? mix : t.cat[k - 1] + CH[k - 1];
+    const long ldx = (k == 1) ? 1 : 2 * CH[k - 1];
+    const float* wp = (k == 1) ? v.w[0] : t.wfwd[k - 1];
+    rc = svs_enc_block_fwd(x, ldx, B, g.h[k - 1], g.w[k - 1], CH[k - 1], wp, v.b[k - 1], nullptr, nullptr, 0.f, t.raw_e[k],
+                           CH[k], CH[k], 0, t.scratch, t.scratch_bytes, stream);
+    if (rc) return rc;
+    const int l = k - 1;
+    if ((rc = svs_bn_stats(t.raw_e[k], CH[k], g.P[k], CH[k], t.bnws, t.bnws_bytes, stream))) return rc;
+    if ((rc = svs_bn_finalize(t.bnws, g.P[k], CH[k], BN_EPS, BN_MOMENTUM, bn_buffers ? bn_buffers + svs_unet_buffer_offset(l, 0) : nullptr,
+                              bn_buffers ? bn_buffers + svs_unet_buffer_offset(l, 1) : nullptr, nbt ? nbt + l : nullptr,
+                              t.mean[l], t.invstd[l], stream))) return rc;
+    float* y = (k == 6) ? t.c6 : t.cat[k] + CH[k];
+    const long ldy = (k == 6) ? 512 : 2 * CH[k];
+    if ((rc = svs_bn_act_apply(t.raw_e[k], CH[k], g.P[k], CH[k], (long)g.h[k] * g.w[k], v.gamma[l], v.beta[l], t.mean[l],
+                               t.invstd[l], LEAKY, nullptr, y, ldy, stream))) return rc;
+  }
+  // decoder: convT (+bias) -> raw; batch stats; BN + ReLU + Dropout2d -> first half of cat[lout]
+  const float* dp = drop;
+  for (int j = 0; j < 5; ++j) {
+    const int lin = 6 - j, lout = 5 - j, l = 6 + j;
+    const float* x = (j == 0) ? t.c6 : t.cat[lin];
+    rc = svs_dec_block_fwd(x, DEC_C[j], B, g.h[lin], g.w[lin], DEC_C[j], t.wfwd[l], v.b[l], nullptr, nullptr, 0.f,
+                           t.raw_d[j], DEC_N[j], g.h[lout], g.w[lout], DEC_N[j], 0, t.scratch, t.scratch_bytes, stream);
+    if (rc) return rc;
+    if ((rc = svs_bn_stats(t.raw_d[j], DEC_N[j], g.P[lout], DEC_N[j], t.bnws, t.bnws_bytes, stream))) return rc;
+    if ((rc = svs_bn_finalize(t.bnws, g.P[lout], DEC_N[j], BN_EPS, BN_MOMENTUM, bn_buffers ? bn_buffers + svs_unet_buffer_offset(l, 0) : nullptr,
+                              bn_buffers ? bn_buffers + svs_unet_buffer_offset(l, 1) : nullptr, nbt ? nbt + l : nullptr,
+                              t.mean[l], t.invstd[l], stream))) return rc;
+    if ((rc = svs_bn_act_apply(t.raw_d[j], DEC_N[j], g.P[lout], DEC_N[j], (long)g.h[lout] * g.w[lout], v.gamma[l], v.beta[l],
+                               t.mean[l], t.invstd[l], 0.f, dp, t.cat[lout], 2 * CH[lout], stream))) return rc;
+    if (dp) dp += (long)B * DEC_N[j];
+  }
+  return svs_out_block_fwd(t.cat[1], 32, B, g.h[1], g.w[1], 32, v.w[11], v.b[11], mask, g.h[0], g.w[0], 1, stream);
+}
+
+static int train_backward_impl(const ParamView& v, float* grads, const float* mix, const float* drop, const Geo& g,
+                               const TrainWs& t, hipStream_t stream) {
+  const int B = g.B;
+  int rc;
+  auto G = [&](int idx) { return grads + svs_unet_param_offset(idx); };
+  // deconv6 (model.py:109,198): dw, db, dx -> dcat[1]
+  if ((rc = svs_dec_block_bwd_weight(t.cat[1], 32, B, g.h[1], g.w[1], 32, t.d_logit, 1, g.h[0], g.w[0], 1, G(44), G(45), t.scratch, t.scratch_bytes, stream))) return rc;
+  if ((rc = svs_dec_block_bwd_data(t.d_logit, 1, B, g.h[0], g.w[0], 1, v.w[11], t.dcat[1], 32, g.h[1], g.w[1], 32, 0, t.scratch, t.scratch_bytes, stream))) return rc;
+  // decoders 5..1
+  long drop_off[5];
+  { long o = 0; for (int j = 0; j < 5; ++j) { drop_off[j] = o; o += (long)B * DEC_N[j]; } }
+  for (int j = 4; j >= 0; --j) {
+    const int lin = 6 - j, lout = 5 - j, l = 6 + j, N = DEC_N[j], C = DEC_C[j];
+    const float* x = (j == 0) ? t.c6 : t.cat[lin];
+    rc = svs_bn_bwd(t.dcat[lout], 2 * CH[lout], t.raw_d[j], N, g.P[lout], N, (long)g.h[lout] * g.w[lout], v.gamma[l], v.beta[l],
+                    t.mean[l], t.invstd[l], 0.f, drop ? drop + drop_off[j] : nullptr, t.d_raw, G(24 + 4 * j + 2), G(24 + 4 * j + 3),
+                    t.bnws, t.bnws_bytes, stream);
+    if (rc) return rc;
+    if ((rc = svs_dec_block_bwd_weight(x, C, B, g.h[lin], g.w[lin], C, t.d_raw, N, g.h[lout], g.w[lout], N, G(24 + 4 * j), G(24 + 4 * j + 1),
+                                       t.scratch, t.scratch_bytes, stream))) return rc;
+    float* dx = (j == 0) ? t.dc6 : t.dcat[lin];
+    if ((rc = svs_dec_block_bwd_data(t.d_raw, N, B, g.h[lout], g.w[lout], N, t.wbwd[l], dx, C, g.h[lin], g.w[lin], C, 0,
+                                     t.scratch, t.scratch_bytes, stream))) return rc;
+  }
+  // encoders 6..1
+  for (int k = 6; k >= 1; --k) {
+    const int l = k - 1, N = CH[k], C = CH[k - 1];
+    const float* dy = (k == 6) ? t.dc6 : t.dcat[k] + CH[k];
+    const long lddy = (k == 6) ? 512 : 2 * CH[k];
+    rc = svs_bn_bwd(dy, lddy, t.raw_e[k], N, g.P[k], N, (long)g.h[k] * g.w[k], v.gamma[l], v.beta[l], t.mean[l], t.invstd[l],
+                    LEAKY, nullptr, t.d_raw, G(4 * l + 2), G(4 * l + 3), t.bnws, t.bnws_bytes, stream);
+    if (rc) return rc;
+    const float* x = (k == 1) ? mix : t.cat[k - 1] + C;
+    const long ldx = (k == 1) ? 1 : 2 * C;
+    if ((rc = svs_enc_block_bwd_weight(t.d_raw, N, B, g.h[k], g.w[k], N, x, ldx, g.h[k - 1], g.w[k - 1], C, G(4 * l), G(4 * l + 1),
+                                       t.scratch, t.scratch_bytes, stream))) return rc;
+    if (k >= 2) {
+      // gradient of the skip half of cat[k-1]: add to what decoder (7-k)'s bwd_data left there
+      if ((rc = svs_enc_block_bwd_data(t.d_raw, N, B, g.h[k], g.w[k], N, t.wbwd[l], t.dcat[k - 1] + C, 2 * C, g.h[k - 1], g.w[k - 1], C, 1,
+                                       t.scratch, t.scratch_bytes, stream))) return rc;
+    }
+  }
+  return SVS_OK;
+}
+
+static int check_train_ws(const char* who, const Geo& g, void* ws, size_t ws_bytes, TrainWs& t) {
+  t = train_layout(g, ws);
+  if (!ws || ws_bytes < t.total || !svs_aligned16(ws)) {
+    svs_set_error("%s: workspace too small (%zu < %zu)", who, ws_bytes, t.total);
+    return SVS_ERR_WORKSPACE;
+  }
+  return SVS_OK;
+}
+
+extern "C" int svs_unet_train_forward(const float* params, float* bn_buffers, int64_t* num_batches_tracked, const float* mix,
+                                      const float* drop, int B, int H, int W, float* mask, void* ws, size_t ws_bytes,
+                                      hipStream_t stream) {
+  Geo g; TrainWs t;
+  int rc = make_geo(B, H, W, g);
+  if (rc) return rc;
+  SVS_REQUIRE(params && mix && mask && svs_aligned16(params) && svs_aligned16(mix) && svs_aligned16(mask), "svs_unet_train_forward: bad pointers");
+  if ((rc = check_train_ws("svs_unet_train_forward", g, ws, ws_bytes, t))) return rc;
+  return train_forward_impl(view_params(params), bn_buffers, num_batches_tracked, mix, drop, g, t, mask, stream);
+}
+
+extern "C" int svs_unet_train_backward(const float* params, float* grads, const float* mix, const float* mask,
+                                       const float* d_mask, const float* drop, int B, int H, int W, void* ws,
+                                       size_t ws_bytes, hipStream_t stream) {
+  Geo g; TrainWs t;
+  int rc = make_geo(B, H, W, g);
+  if (rc) return rc;
+  SVS_REQUIRE(params && grads && mix && mask && d_mask && svs_aligned16(grads), "svs_unet_train_backward: bad pointers");
+  if ((rc = check_train_ws("svs_unet_train_backward", g, ws, ws_bytes, t))) return rc;
+  if ((rc = svs_sigmoid_bwd_run(mask, d_mask, g.P[0], t.d_logit, stream))) return rc;
+  return train_backward_impl(view_params(params), grads, mix, drop, g, t, stream);
+}
+
+extern "C" int svs_unet_train_fwd_bwd(const float* params, float* grads, float* bn_buffers, int64_t* num_batches_tracked,
+                                      const float* mix, const float* voc, const float* drop, int B, int H, int W,
+                                      float loss_scale, float* mask, float* loss, void* ws, size_t ws_bytes,
+                                      hipStream_t stream) {
+  Geo g; TrainWs t;
+  int rc = make_geo(B, H, W, g);
+  if (rc) return rc;
+  SVS_REQUIRE(params && grads && mix && voc && loss && svs_aligned16(params) && svs_aligned16(grads) && svs_aligned16(mix),
+              "svs_unet_train_fwd_bwd: bad pointers");
+  if ((rc = check_train_ws("svs_unet_train_fwd_bwd", g, ws, ws_bytes, t))) return rc;
+  float* m = mask ? mask : t.mask;
+  const ParamView v = view_params(params);
+  if ((rc = train_forward_impl(v, bn_buffers, num_batches_tracked, mix, drop, g, t, m, stream))) return rc;
+  if ((rc = svs_l1_mask_loss_fwd_bwd(m, mix, voc, g.P[0], loss_scale, t.d_logit, loss, t.bnws, t.bnws_bytes, stream))) return rc;
+  return train_backward_impl(v, grads, mix, drop, g, t, stream);
+}

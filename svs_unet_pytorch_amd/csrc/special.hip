@@ -1,0 +1,276 @@
+// The single-channel ends of the U-Net (bandwidth-bound, no MFMA), gfx950:
+//   conv_c1_kernel    1 -> COUT channels, 5x5 stride-2 gather.  conv1 forward (reference model.py:47-51)
+//                     and deconv6 backward-data (model.py:109).
+//   deconv_to1_kernel CIN -> 1 channel transposed conv + sigmoid.  deconv6 forward (model.py:198-200).
+//   wgrad_c1_kernel   dw[cs][tap] = sum_pix S[pix][cs] * L[window(pix, tap)], L single-channel.
+//                     conv1 / deconv6 weight gradients.
+// All three give each pixel's channel vector to COUT/4 (CIN/4) adjacent lanes as float4, so the wide
+// side is read/written in contiguous 16-byte pieces; the single-channel image is read through L1.
+// Bound: HBM.  Algorithmic bytes: the NHWC tensor once + the 1-channel image once.
+#include "common.h"
+
+struct C1Args {
+  const float* x; int B, H, W;            // (B,H,W) single channel
+  const float* w;                         // [COUT][25]  (torch (COUT,1,5,5) == gather packing with C=1)
+  const float* bias; const float* scale; const float* shift; float slope;
+  float* y; long ldy; int Ho, Wo; int accumulate;
+};
+
+template <int COUT>
+__global__ __launch_bounds__(256) void conv_c1_kernel(C1Args p) {
+  constexpr int G = COUT / 4;
+  __shared__ __attribute__((aligned(16))) float wl[25 * COUT];   // [tap][n]
+  for (int i = threadIdx.x; i < 25 * COUT; i += 256) {
+    const int n = i / 25, tap = i - n * 25;
+    wl[tap * COUT + n] = p.w[i];
+  }
+  __syncthreads();
+  const long total = (long)p.B * p.Ho * p.Wo * G;
+  for (long gid = (long)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (long)gridDim.x * 256) {
+    const int cg = (int)(gid % G);
+    const long pix = gid / G;
+    const int ow = (int)(pix % p.Wo);
+    const long tmp = pix / p.Wo;
+    const int oh = (int)(tmp % p.Ho);
+    const long b = tmp / p.Ho;
+    const float* img = p.x + b * p.H * p.W;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kh = 0; kh < 5; ++kh) {
+      const int ih = 2 * oh - 2 + kh;
+      if ((unsigned)ih >= (unsigned)p.H) continue;
+#pragma unroll
+      for (int kw = 0; kw < 5; ++kw) {
+        const int iw = 2 * ow - 2 + kw;
+        if ((unsigned)iw >= (unsigned)p.W) continue;
+        const float v = img[(long)ih * p.W + iw];
+        const f32x4 w4 = *(const f32x4*)(&wl[(kh * 5 + kw) * COUT + cg * 4]);
+        acc += w4 * v;
+      }
+    }
+    const int n = cg * 4;
+    float* dst = p.y + pix * p.ldy + n;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float v = acc[k];
+      if (p.bias) v += p.bias[n + k];
+      if (p.scale) {
+        v = v * p.scale[n + k] + p.shift[n + k];
+        v = v > 0.f ? v : v * p.slope;
+      }
+      if (p.accumulate) v += dst[k];
+      acc[k] = v;
+    }
+    *(f32x4*)dst = acc;
+  }
+}
+
+int svs_conv_c1_run(const float* x, int B, int H, int W, const float* w, const float* bias, const float* scale,
+                    const float* shift, float slope, float* y, long ldy, int N, int accumulate, hipStream_t stream,
+                    const char* who) {
+  SVS_REQUIRE(x && w && y, "%s: null pointer", who);
+  SVS_REQUIRE(N == 16 || N == 32, "%s: single-channel conv supports N=16/32, got %d", who, N);
+  SVS_REQUIRE(ldy >= N && ldy % 4 == 0 && svs_aligned16(y), "%s: bad output view", who);
+  C1Args a{x, B, H, W, w, bias, scale, shift, slope, y, ldy, svs_conv_out(H), svs_conv_out(W), accumulate};
+  const long total = (long)B * a.Ho * a.Wo * (N / 4);
+  int grid = (int)((total + 255) / 256);
+  if (grid > 8192) grid = 8192;
+  if (N == 16) hipLaunchKernelGGL(conv_c1_kernel<16>, dim3(grid), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(conv_c1_kernel<32>, dim3(grid), dim3(256), 0, stream, a);
+  SVS_CHECK_LAUNCH("conv_c1");
+  return SVS_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+struct To1Args {
+  const float* x; long ldx; int B, H, W;   // (B,H,W,CIN)
+  const float* w;                          // torch (CIN,1,5,5) = [c][25]
+  const float* bias;                       // device scalar or null
+  float* y; int Ho, Wo; int sigmoid;
+};
+
+template <int CIN>
+__global__ __launch_bounds__(256) void deconv_to1_kernel(To1Args p) {
+  constexpr int G = CIN / 4;
+  __shared__ __attribute__((aligned(16))) float wl[25 * CIN];    // [tap][c]
+  for (int i = threadIdx.x; i < 25 * CIN; i += 256) {
+    const int c = i / 25, tap = i - c * 25;
+    wl[tap * CIN + c] = p.w[i];
+  }
+  __syncthreads();
+  const float bias = p.bias ? p.bias[0] : 0.f;
+  const long quads = (long)p.B * p.H * p.W;
+  const long total = (quads * G + 255) / 256 * 256;   // keep whole waves alive for the shuffles
+  for (long gid = (long)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (long)gridDim.x * 256) {
+    const int cg = (int)(gid % G);
+    const long qd = gid / G;
+    const bool live = qd < quads;
+    const long qq = live ? qd : 0;
+    const int c = (int)(qq % p.W);
+    const long tmp = qq / p.W;
+    const int a = (int)(tmp % p.H);
+    const long b = tmp / p.H;
+    float o[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+    for (int dh = -1; dh <= 1; ++dh) {
+      const int ih = a + dh;
+#pragma unroll
+      for (int dw = -1; dw <= 1; ++dw) {
+        const int iw = c + dw;
+        if (!live || (unsigned)ih >= (unsigned)p.H || (unsigned)iw >= (unsigned)p.W) continue;
+        const f32x4 v = *(const f32x4*)(p.x + ((b * p.H + ih) * p.W + iw) * p.ldx + cg * 4);
+        const int th = 1 - dh, tw = 1 - dw;
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+          const int kh = ph + 2 * th;
+          if (kh > 4) continue;
+#pragma unroll
+          for (int pw = 0; pw < 2; ++pw) {
+            const int kw = pw + 2 * tw;
+            if (kw > 4) continue;
+            const f32x4 w4 = *(const f32x4*)(&wl[(kh * 5 + kw) * CIN + cg * 4]);
+            o[ph][pw] += v[0] * w4[0] + v[1] * w4[1] + v[2] * w4[2] + v[3] * w4[3];
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+      for (int pw = 0; pw < 2; ++pw)
+#pragma unroll
+        for (int s = 1; s < G; s <<= 1) o[ph][pw] += __shfl_xor(o[ph][pw], s, 64);
+    if (live && cg < 4) {
+      const int ph = cg >> 1, pw = cg & 1;
+      float v = (cg == 0) ? o[0][0] : (cg == 1) ? o[0][1] : (cg == 2) ? o[1][0] : o[1][1];
+      const int oh = 2 * a + ph, ow = 2 * c + pw;
+      if (oh < p.Ho && ow < p.Wo) {
+        v += bias;
+        if (p.sigmoid) v = 1.f / (1.f + __expf(-v));
+        p.y[(b * p.Ho + oh) * p.Wo + ow] = v;
+      }
+    }
+  }
+}
+
+int svs_deconv_to1_run(const float* x, long ldx, int B, int H, int W, int C, const float* w, const float* bias,
+                       float* y, int Ho, int Wo, int apply_sigmoid, hipStream_t stream, const char* who) {
+  SVS_REQUIRE(x && w && y, "%s: null pointer", who);
+  SVS_REQUIRE(C == 32 || C == 16, "%s: supports C=16/32, got %d", who, C);
+  SVS_REQUIRE((Ho == 2 * H || Ho == 2 * H - 1) && (Wo == 2 * W || Wo == 2 * W - 1), "%s: output %dx%d unreachable from %dx%d", who, Ho, Wo, H, W);
+  SVS_REQUIRE(ldx >= C && ldx % 4 == 0 && svs_aligned16(x), "%s: bad input view", who);
+  To1Args a{x, ldx, B, H, W, w, bias, y, Ho, Wo, apply_sigmoid};
+  const long total = (long)B * H * W * (C / 4);
+  int grid = (int)((total + 255) / 256);
+  if (grid > 8192) grid = 8192;
+  if (C == 32) hipLaunchKernelGGL(deconv_to1_kernel<32>, dim3(grid), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(deconv_to1_kernel<16>, dim3(grid), dim3(256), 0, stream, a);
+  SVS_CHECK_LAUNCH("deconv_to1");
+  return SVS_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+struct WgC1Args {
+  const float* s; long lds; int B, Hs, Ws;   // (B,Hs,Ws,CS)
+  const float* l; int Hl, Wl;                // (B,Hl,Wl) single channel
+  float* slab;                               // [gridDim.x][CS*25]
+  long pix_per_block;
+};
+
+template <int CS>
+__global__ __launch_bounds__(256) void wgrad_c1_kernel(WgC1Args p) {
+  constexpr int G = CS / 4;
+  constexpr int PL = 256 / G;                // pixels per sweep
+  __shared__ float red[4][25 * CS];
+  const int t = threadIdx.x;
+  const int cg = t % G, pl = t / G;
+  const long P = (long)p.B * p.Hs * p.Ws;
+  const long p0 = (long)blockIdx.x * p.pix_per_block;
+  long p1 = p0 + p.pix_per_block;
+  if (p1 > P) p1 = P;
+  f32x4 acc[25];
+#pragma unroll
+  for (int k = 0; k < 25; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (long pix = p0 + pl; pix < p1; pix += PL) {
+    const int j = (int)(pix % p.Ws);
+    const long tmp = pix / p.Ws;
+    const int i = (int)(tmp % p.Hs);
+    const long b = tmp / p.Hs;
+    const f32x4 s4 = *(const f32x4*)(p.s + pix * p.lds + cg * 4);
+    const float* img = p.l + b * p.Hl * p.Wl;
+#pragma unroll
+    for (int kh = 0; kh < 5; ++kh) {
+      const int ih = 2 * i - 2 + kh;
+#pragma unroll
+      for (int kw = 0; kw < 5; ++kw) {
+        const int iw = 2 * j - 2 + kw;
+        float lv = 0.f;
+        if ((unsigned)ih < (unsigned)p.Hl && (unsigned)iw < (unsigned)p.Wl) lv = img[(long)ih * p.Wl + iw];
+        acc[kh * 5 + kw] += s4 * lv;
+      }
+    }
+  }
+  // lanes with equal cg inside a wave, then the 4 waves through LDS (fixed order: reproducible)
+#pragma unroll
+  for (int k = 0; k < 25; ++k)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float v = acc[k][c];
+#pragma unroll
+      for (int s = G; s < 64; s <<= 1) v += __shfl_xor(v, s, 64);
+      acc[k][c] = v;
+    }
+  const int lane = t & 63, wave = t >> 6;
+  if (lane < G) {
+#pragma unroll
+    for (int k = 0; k < 25; ++k)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) red[wave][(lane * 4 + c) * 25 + k] = acc[k][c];
+  }
+  __syncthreads();
+  float* out = p.slab + (long)blockIdx.x * (25 * CS);
+  for (int i = t; i < 25 * CS; i += 256) out[i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+}
+
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slab, int nslab, long n,
+                                                           float* __restrict__ out) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float s = 0.f;
+    for (int z = 0; z < nslab; ++z) s += slab[(long)z * n + i];
+    out[i] = s;
+  }
+}
+
+static int wgrad_c1_blocks(long P) {
+  long nb = (P + 1023) / 1024;
+  if (nb > 2048) nb = 2048;
+  if (nb < 1) nb = 1;
+  return (int)nb;
+}
+
+size_t svs_wgrad_c1_workspace(int B, int Hs, int Ws, int Cs) {
+  return (size_t)wgrad_c1_blocks((long)B * Hs * Ws) * 25 * Cs * sizeof(float);
+}
+
+int svs_wgrad_c1_run(const float* s, long lds, int B, int Hs, int Ws, int Cs, const float* l, int Hl, int Wl,
+                     float* dw, void* ws, size_t ws_bytes, hipStream_t stream, const char* who) {
+  SVS_REQUIRE(s && l && dw, "%s: null pointer", who);
+  SVS_REQUIRE(Cs == 16 || Cs == 32, "%s: supports Cs=16/32, got %d", who, Cs);
+  SVS_REQUIRE(Hs == svs_conv_out(Hl) && Ws == svs_conv_out(Wl), "%s: grid mismatch", who);
+  SVS_REQUIRE(lds >= Cs && lds % 4 == 0 && svs_aligned16(s), "%s: bad view", who);
+  const long P = (long)B * Hs * Ws;
+  const int nb = wgrad_c1_blocks(P);
+  const size_t need = (size_t)nb * 25 * Cs * sizeof(float);
+  if (!ws || ws_bytes < need) {
+    svs_set_error("%s: workspace too small (%zu < %zu)", who, ws_bytes, need);
+    return SVS_ERR_WORKSPACE;
+  }
+  WgC1Args a{s, lds, B, Hs, Ws, l, Hl, Wl, (float*)ws, (P + nb - 1) / nb};
+  if (Cs == 16) hipLaunchKernelGGL(wgrad_c1_kernel<16>, dim3(nb), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(wgrad_c1_kernel<32>, dim3(nb), dim3(256), 0, stream, a);
+  SVS_CHECK_LAUNCH("wgrad_c1");
+  const long n = 25L * Cs;
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const float*)ws, nb, n, dw);
+  SVS_CHECK_LAUNCH("reduce_slabs");
+  return SVS_OK;
+}

@@ -1,0 +1,450 @@
+"""Per-kernel parity (-m gpu): every C-ABI block entry point against a plain PyTorch fp64 CPU
+computation of the same op (torch.nn.functional on NCHW tensors), on seeded inputs.  Tolerances are
+relative to the output's magnitude; fp32 MFMA is an exact fmaf chain, so the only error is
+summation order (~1e-6 relative)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from svs_unet_pytorch_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def L():
+    return _lib.lib()
+
+
+def S():
+    return _lib.stream_ptr()
+
+
+def rnd(shape, seed, lo=-1.0, hi=1.0):
+    n = int(np.prod(shape))
+    return torch.from_numpy((synth.uniform(seed, n) * (hi - lo) + lo).reshape(shape).astype(np.float32))
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def relerr(got, want):
+    want = want.double()
+    return ((got.double().cpu() - want).abs().max() / want.abs().max().clamp_min(1e-30)).item()
+
+
+def ws_tensor(nbytes):
+    return torch.empty(max(int(nbytes), 16) + 4096, dtype=torch.uint8, device=DEV)
+
+
+def pack_gather(w):      # (N,C,5,5) -> device packed
+    N, C = w.shape[:2]
+    wd = w.to(DEV).contiguous()
+    out = torch.empty(N * C * 25, device=DEV)
+    _lib.check(L().svs_pack_weight_gather(wd.data_ptr(), out.data_ptr(), N, C, S()))
+    return out
+
+
+def pack_parity(w):      # (C,N,5,5) -> device packed
+    C, N = w.shape[:2]
+    wd = w.to(DEV).contiguous()
+    out = torch.empty(N * C * 25, device=DEV)
+    _lib.check(L().svs_pack_weight_parity(wd.data_ptr(), out.data_ptr(), C, N, S()))
+    return out
+
+
+def test_pack_layouts(report):
+    w = rnd((32, 16, 5, 5), 1)
+    got = pack_gather(w).cpu().view(32, 25, 16)
+    want = w.permute(0, 2, 3, 1).reshape(32, 25, 16)
+    assert torch.equal(got, want)
+    wt = rnd((16, 32, 5, 5), 2)      # (C,N,5,5)
+    got = pack_parity(wt).cpu()
+    off = 0
+    for ph in (0, 1):
+        for pw in (0, 1):
+            sub = wt[:, :, ph::2, pw::2]                      # (C,N,nth,ntw)
+            want = sub.permute(1, 2, 3, 0).reshape(-1)        # [n][th][tw][c]
+            assert torch.equal(got[off:off + want.numel()], want), (ph, pw)
+            off += want.numel()
+    assert off == wt.numel()
+
+
+ENC_CASES = [
+    # B, H, W, C, N
+    (2, 64, 32, 16, 32),      # conv2-like, cfg 256x32
+    (2, 32, 16, 32, 64),      # conv3-like, 64x64 / 128x64
+    (3, 16, 8, 64, 128),      # conv4-like, 128x128
+    (2, 8, 4, 128, 256),      # conv5-like, small M, split-K
+    (1, 16, 4, 256, 512),     # conv6 at B=1 (M=16): 32x128 tile, split-K
+    (1, 33, 9, 16, 32),       # odd sizes
+    (4, 128, 32, 16, 16),     # N=16 tile
+    (8, 64, 32, 32, 64),      # larger M for 128x64
+]
+
+
+@pytest.mark.parametrize("B,H,W,C,N", ENC_CASES)
+def test_enc_block_fwd(B, H, W, C, N, report):
+    x = rnd((B, C, H, W), 10)
+    w = rnd((N, C, 5, 5), 11, -0.1, 0.1)
+    b = rnd((N,), 12)
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    want = F.conv2d(x.double(), w.double(), b.double(), stride=2, padding=2)
+    xd = nhwc(x).to(DEV)
+    wp = pack_gather(w)
+    bd = b.to(DEV)
+    # write into the second half of a wider buffer (the skip-concat layout)
+    y = torch.full((B, Ho, Wo, 2 * N), 7.0, device=DEV)
+    ws = ws_tensor(L().svs_enc_block_workspace_bytes(B, H, W, C, N))
+    _lib.check(L().svs_enc_block_fwd(xd.data_ptr(), C, B, H, W, C, wp.data_ptr(), bd.data_ptr(), None, None, 0.0,
+                                     y.data_ptr() + 4 * N, 2 * N, N, 0, ws.data_ptr(), ws.numel(), S()))
+    torch.cuda.synchronize()
+    assert torch.all(y[..., :N] == 7.0), "wrote outside its channel slice"
+    e = relerr(nchw(y[..., N:]), want)
+    assert report(f"enc_fwd raw B{B} {H}x{W} C{C} N{N}", e, 2e-5)
+    # eval epilogue: scale/shift + leaky, bias folded by the caller -> here bias=None
+    sc, sh = rnd((N,), 13, 0.5, 1.5), rnd((N,), 14)
+    want2 = F.leaky_relu(F.conv2d(x.double(), w.double(), None, stride=2, padding=2) * sc.double()[None, :, None, None]
+                         + sh.double()[None, :, None, None], 0.2)
+    y2 = torch.empty((B, Ho, Wo, N), device=DEV)
+    scd, shd = sc.to(DEV), sh.to(DEV)
+    _lib.check(L().svs_enc_block_fwd(xd.data_ptr(), C, B, H, W, C, wp.data_ptr(), None, scd.data_ptr(), shd.data_ptr(), 0.2,
+                                     y2.data_ptr(), N, N, 0, ws.data_ptr(), ws.numel(), S()))
+    e = relerr(nchw(y2), want2)
+    assert report(f"enc_fwd epi B{B} {H}x{W} C{C} N{N}", e, 2e-5)
+    # accumulate
+    _lib.check(L().svs_enc_block_fwd(xd.data_ptr(), C, B, H, W, C, wp.data_ptr(), None, scd.data_ptr(), shd.data_ptr(), 0.2,
+                                     y2.data_ptr(), N, N, 1, ws.data_ptr(), ws.numel(), S()))
+    e = relerr(nchw(y2), 2 * want2)
+    assert report(f"enc_fwd acc B{B} {H}x{W} C{C} N{N}", e, 2e-5)
+
+
+def test_enc_block_fwd_c1(report):
+    for (B, H, W, N) in ((2, 64, 32, 16), (1, 33, 17, 16), (2, 32, 32, 32)):
+        x = rnd((B, 1, H, W), 20, 0, 1)
+        w = rnd((N, 1, 5, 5), 21, -0.2, 0.2)
+        b = rnd((N,), 22)
+        want = F.conv2d(x.double(), w.double(), b.double(), stride=2, padding=2)
+        Ho, Wo = (H + 1) // 2, (W + 1) // 2
+        y = torch.empty((B, Ho, Wo, N), device=DEV)
+        xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+        _lib.check(L().svs_enc_block_fwd(xd.data_ptr(), 1, B, H, W, 1, wd.data_ptr(), bd.data_ptr(), None, None, 0.0,
+                                         y.data_ptr(), N, N, 0, None, 0, S()))
+        assert report(f"enc_fwd_c1 B{B} {H}x{W} N{N}", relerr(nchw(y), want), 1e-5)
+
+
+DEC_CASES = [
+    # B, H, W, C, N, Ho, Wo
+    (2, 8, 2, 512, 256, 16, 4),     # deconv1
+    (2, 16, 4, 512, 128, 32, 8),    # deconv2
+    (2, 16, 8, 256, 64, 32, 16),    # deconv3-like
+    (2, 32, 16, 128, 32, 64, 32),   # deconv4-like
+    (2, 64, 16, 64, 16, 128, 32),   # deconv5-like (N=16)
+    (1, 9, 2, 64, 64, 17, 4),       # odd height (513-row path)
+    (1, 5, 7, 32, 32, 9, 13),       # odd both
+]
+
+
+@pytest.mark.parametrize("B,H,W,C,N,Ho,Wo", DEC_CASES)
+def test_dec_block_fwd(B, H, W, C, N, Ho, Wo, report):
+    x = rnd((B, C, H, W), 30)
+    w = rnd((C, N, 5, 5), 31, -0.1, 0.1)
+    b = rnd((N,), 32)
+    op = (Ho - (2 * H - 1), Wo - (2 * W - 1))
+    want = F.conv_transpose2d(x.double(), w.double(), b.double(), stride=2, padding=2, output_padding=op)
+    xd = nhwc(x).to(DEV)
+    wp = pack_parity(w)
+    bd = b.to(DEV)
+    y = torch.full((B, Ho, Wo, 2 * N), -3.0, device=DEV)
+    ws = ws_tensor(L().svs_dec_block_workspace_bytes(B, H, W, C, Ho, Wo, N))
+    _lib.check(L().svs_dec_block_fwd(xd.data_ptr(), C, B, H, W, C, wp.data_ptr(), bd.data_ptr(), None, None, 0.0,
+                                     y.data_ptr(), 2 * N, Ho, Wo, N, 0, ws.data_ptr(), ws.numel(), S()))
+    torch.cuda.synchronize()
+    assert torch.all(y[..., N:] == -3.0)
+    assert report(f"dec_fwd raw B{B} {H}x{W}->{Ho}x{Wo} C{C} N{N}", relerr(nchw(y[..., :N]), want), 2e-5)
+    sc, sh = rnd((N,), 33, 0.5, 1.5), rnd((N,), 34)
+    want2 = F.relu(F.conv_transpose2d(x.double(), w.double(), None, stride=2, padding=2, output_padding=op)
+                   * sc.double()[None, :, None, None] + sh.double()[None, :, None, None])
+    y2 = torch.empty((B, Ho, Wo, N), device=DEV)
+    scd, shd = sc.to(DEV), sh.to(DEV)
+    _lib.check(L().svs_dec_block_fwd(xd.data_ptr(), C, B, H, W, C, wp.data_ptr(), None, scd.data_ptr(), shd.data_ptr(), 0.0,
+                                     y2.data_ptr(), N, Ho, Wo, N, 0, ws.data_ptr(), ws.numel(), S()))
+    assert report(f"dec_fwd epi B{B} {H}x{W}->{Ho}x{Wo} C{C} N{N}", relerr(nchw(y2), want2), 2e-5)
+
+
+def test_out_block_fwd(report):
+    for (B, H, W, Ho, Wo) in ((2, 32, 16, 64, 32), (1, 17, 8, 33, 16), (1, 9, 5, 17, 9)):
+        C = 32
+        x = rnd((B, C, H, W), 40)
+        w = rnd((C, 1, 5, 5), 41, -0.2, 0.2)
+        b = rnd((1,), 42)
+        op = (Ho - (2 * H - 1), Wo - (2 * W - 1))
+        want = torch.sigmoid(F.conv_transpose2d(x.double(), w.double(), b.double(), stride=2, padding=2, output_padding=op))
+        xd, wd, bd = nhwc(x).to(DEV), w.to(DEV), b.to(DEV)
+        y = torch.empty((B, 1, Ho, Wo), device=DEV)
+        _lib.check(L().svs_out_block_fwd(xd.data_ptr(), C, B, H, W, C, wd.data_ptr(), bd.data_ptr(), y.data_ptr(), Ho, Wo, 1, S()))
+        assert report(f"out_block B{B} {H}x{W}->{Ho}x{Wo}", relerr(y, want), 1e-5)
+
+
+@pytest.mark.parametrize("B,H,W,C,N", [(2, 32, 16, 32, 64), (2, 16, 8, 128, 256), (1, 33, 9, 16, 32), (4, 64, 32, 16, 32)])
+def test_enc_block_bwd(B, H, W, C, N, report):
+    x = rnd((B, C, H, W), 50).double().requires_grad_(True)
+    w = rnd((N, C, 5, 5), 51, -0.1, 0.1).double().requires_grad_(True)
+    b = rnd((N,), 52).double().requires_grad_(True)
+    y = F.conv2d(x, w, b, stride=2, padding=2)
+    dy = rnd(tuple(y.shape), 53)
+    y.backward(dy.double())
+    Ho, Wo = y.shape[-2:]
+    dyd = nhwc(dy).to(DEV)
+    xd = nhwc(x.detach().float()).to(DEV)
+    wpar = pack_parity(w.detach().float())          # conv weight (N,C,..) read as (in=N, out=C)
+    dx = torch.zeros((B, H, W, C), device=DEV)
+    ws = ws_tensor(max(L().svs_dec_block_workspace_bytes(B, Ho, Wo, N, H, W, C),
+                       L().svs_block_bwd_weight_workspace_bytes(B, Ho, Wo, N, C)))
+    _lib.check(L().svs_enc_block_bwd_data(dyd.data_ptr(), N, B, Ho, Wo, N, wpar.data_ptr(), dx.data_ptr(), C, H, W, C, 0,
+                                          ws.data_ptr(), ws.numel(), S()))
+    assert report(f"enc_bwd_data B{B} {H}x{W} C{C} N{N}", relerr(nchw(dx), x.grad), 2e-5)
+    dw = torch.empty((N, C, 5, 5), device=DEV)
+    db = torch.empty((N,), device=DEV)
+    _lib.check(L().svs_enc_block_bwd_weight(dyd.data_ptr(), N, B, Ho, Wo, N, xd.data_ptr(), C, H, W, C, dw.data_ptr(), db.data_ptr(),
+                                            ws.data_ptr(), ws.numel(), S()))
+    assert report(f"enc_bwd_weight B{B} {H}x{W} C{C} N{N}", relerr(dw, w.grad), 2e-5)
+    assert report(f"enc_bwd_bias B{B} {H}x{W} C{C} N{N}", relerr(db, b.grad), 2e-5)
+
+
+@pytest.mark.parametrize("B,H,W,C,N,Ho,Wo", [(2, 16, 4, 512, 128, 32, 8), (2, 32, 16, 128, 32, 64, 32), (2, 64, 16, 64, 16, 128, 32),
+                                             (1, 9, 2, 64, 64, 17, 4)])
+def test_dec_block_bwd(B, H, W, C, N, Ho, Wo, report):
+    x = rnd((B, C, H, W), 60).double().requires_grad_(True)
+    w = rnd((C, N, 5, 5), 61, -0.1, 0.1).double().requires_grad_(True)
+    b = rnd((N,), 62).double().requires_grad_(True)
+    op = (Ho - (2 * H - 1), Wo - (2 * W - 1))
+    y = F.conv_transpose2d(x, w, b, stride=2, padding=2, output_padding=op)
+    dy = rnd(tuple(y.shape), 63)
+    y.backward(dy.double())
+    dyd = nhwc(dy).to(DEV)
+    xd = nhwc(x.detach().float()).to(DEV)
+    wgat = pack_gather(w.detach().float())          # convT weight (C,N,..) read as (n=C, c=N)
+    dx = torch.zeros((B, H, W, C), device=DEV)
+    ws = ws_tensor(max(L().svs_enc_block_workspace_bytes(B, Ho, Wo, N, C),
+                       L().svs_block_bwd_weight_workspace_bytes(B, H, W, C, N)))
+    _lib.check(L().svs_dec_block_bwd_data(dyd.data_ptr(), N, B, Ho, Wo, N, wgat.data_ptr(), dx.data_ptr(), C, H, W, C, 0,
+                                          ws.data_ptr(), ws.numel(), S()))
+    assert report(f"dec_bwd_data B{B} {H}x{W} C{C} N{N}", relerr(nchw(dx), x.grad), 2e-5)
+    dw = torch.empty((C, N, 5, 5), device=DEV)
+    db = torch.empty((N,), device=DEV)
+    _lib.check(L().svs_dec_block_bwd_weight(xd.data_ptr(), C, B, H, W, C, dyd.data_ptr(), N, Ho, Wo, N, dw.data_ptr(), db.data_ptr(),
+                                            ws.data_ptr(), ws.numel(), S()))
+    assert report(f"dec_bwd_weight B{B} {H}x{W} C{C} N{N}", relerr(dw, w.grad), 2e-5)
+    assert report(f"dec_bwd_bias B{B} {H}x{W} C{C} N{N}", relerr(db, b.grad), 2e-5)
+
+
+def test_single_channel_bwd(report):
+    # conv1: dw, db ; deconv6: dw, db, dx
+    B, H, W = 2, 64, 32
+    x = rnd((B, 1, H, W), 70, 0, 1).double()
+    w = rnd((16, 1, 5, 5), 71, -0.2, 0.2).double().requires_grad_(True)
+    b = rnd((16,), 72).double().requires_grad_(True)
+    y = F.conv2d(x, w, b, stride=2, padding=2)
+    dy = rnd(tuple(y.shape), 73)
+    y.backward(dy.double())
+    dyd, xd = nhwc(dy).to(DEV), x.float().to(DEV)
+    dw, db = torch.empty((16, 1, 5, 5), device=DEV), torch.empty(16, device=DEV)
+    ws = ws_tensor(L().svs_block_bwd_weight_workspace_bytes(B, H // 2, W // 2, 16, 1))
+    _lib.check(L().svs_enc_block_bwd_weight(dyd.data_ptr(), 16, B, H // 2, W // 2, 16, xd.data_ptr(), 1, H, W, 1, dw.data_ptr(),
+                                            db.data_ptr(), ws.data_ptr(), ws.numel(), S()))
+    assert report("conv1_bwd_weight", relerr(dw, w.grad), 2e-5)
+    assert report("conv1_bwd_bias", relerr(db, b.grad), 2e-5)
+
+    C = 32
+    x = rnd((B, C, H // 2, W // 2), 74).double().requires_grad_(True)
+    w = rnd((C, 1, 5, 5), 75, -0.2, 0.2).double().requires_grad_(True)
+    b = rnd((1,), 76).double().requires_grad_(True)
+    y = F.conv_transpose2d(x, w, b, stride=2, padding=2, output_padding=1)
+    dy = rnd(tuple(y.shape), 77)
+    y.backward(dy.double())
+    xd, dyd, wd = nhwc(x.detach().float()).to(DEV), dy.to(DEV), w.detach().float().to(DEV)
+    dw, db = torch.empty((C, 1, 5, 5), device=DEV), torch.empty(1, device=DEV)
+    dx = torch.empty((B, H // 2, W // 2, C), device=DEV)
+    ws = ws_tensor(L().svs_block_bwd_weight_workspace_bytes(B, H // 2, W // 2, C, 1))
+    _lib.check(L().svs_dec_block_bwd_weight(xd.data_ptr(), C, B, H // 2, W // 2, C, dyd.data_ptr(), 1, H, W, 1, dw.data_ptr(),
+                                            db.data_ptr(), ws.data_ptr(), ws.numel(), S()))
+    _lib.check(L().svs_dec_block_bwd_data(dyd.data_ptr(), 1, B, H, W, 1, wd.data_ptr(), dx.data_ptr(), C, H // 2, W // 2, C, 0,
+                                          ws.data_ptr(), ws.numel(), S()))
+    assert report("deconv6_bwd_weight", relerr(dw, w.grad), 2e-5)
+    assert report("deconv6_bwd_bias", relerr(db, b.grad), 2e-5)
+    assert report("deconv6_bwd_data", relerr(nchw(dx), x.grad), 2e-5)
+
+
+@pytest.mark.parametrize("B,H,W,C,slope,use_drop", [(4, 16, 8, 64, 0.2, False), (3, 8, 4, 256, 0.0, True), (2, 64, 32, 16, 0.2, False),
+                                                     (2, 4, 2, 512, 0.0, True)])
+def test_bn_train_fwd_bwd(B, H, W, C, slope, use_drop, report):
+    x = (rnd((B, C, H, W), 80) * 2 + 0.3).double().requires_grad_(True)
+    gamma = rnd((C,), 81, 0.5, 1.5).double().requires_grad_(True)
+    beta = rnd((C,), 82, -0.2, 0.2).double().requires_grad_(True)
+    rm0, rv0 = rnd((C,), 83, -0.1, 0.1), rnd((C,), 84, 0.5, 1.5)
+    rm, rv = rm0.clone().double(), rv0.clone().double()
+    drop = None
+    if use_drop:
+        bits = (synth.u32(5, np.arange(B * C, dtype=np.uint64)) >> np.uint32(31)).astype(np.float32) * 2
+        drop = torch.from_numpy(bits.reshape(B, C))
+    z = F.batch_norm(x, rm, rv, gamma, beta, training=True, momentum=0.1, eps=1e-5)
+    a = F.leaky_relu(z, slope)
+    if drop is not None:
+        a = a * drop.double()[:, :, None, None]
+    dy = rnd(tuple(a.shape), 85)
+    a.backward(dy.double())
+
+    P = B * H * W
+    xd = nhwc(x.detach().float()).to(DEV)
+    gd, bd = gamma.detach().float().to(DEV), beta.detach().float().to(DEV)
+    rmd, rvd = rm0.to(DEV), rv0.to(DEV)
+    nbt = torch.tensor([3], dtype=torch.int64, device=DEV)
+    mean, invstd = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    ws = ws_tensor(L().svs_bn_workspace_bytes(P, C))
+    y = torch.empty((B, H, W, 2 * C), device=DEV)
+    dd = drop.to(DEV).contiguous() if drop is not None else None
+    _lib.check(L().svs_bn_stats(xd.data_ptr(), C, P, C, ws.data_ptr(), ws.numel(), S()))
+    _lib.check(L().svs_bn_finalize(ws.data_ptr(), P, C, 1e-5, 0.1, rmd.data_ptr(), rvd.data_ptr(), nbt.data_ptr(), mean.data_ptr(),
+                                   invstd.data_ptr(), S()))
+    _lib.check(L().svs_bn_act_apply(xd.data_ptr(), C, P, C, H * W, gd.data_ptr(), bd.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                    slope, _lib.ptr(dd), y.data_ptr() + 4 * C, 2 * C, S()))
+    tag = f"bn B{B} {H}x{W} C{C}"
+    assert report(tag + " fwd", relerr(nchw(y[..., C:]), a.detach()), 1e-5)
+    assert report(tag + " running_mean", relerr(rmd, rm), 1e-5)
+    assert report(tag + " running_var", relerr(rvd, rv), 1e-5)
+    assert int(nbt.item()) == 4
+    dyw = torch.zeros((B, H, W, 2 * C), device=DEV)
+    dyw[..., C:] = nhwc(dy).to(DEV)
+    d_raw = torch.empty((B, H, W, C), device=DEV)
+    dg, db = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    _lib.check(L().svs_bn_bwd(dyw.data_ptr() + 4 * C, 2 * C, xd.data_ptr(), C, P, C, H * W, gd.data_ptr(), bd.data_ptr(), mean.data_ptr(),
+                              invstd.data_ptr(), slope, _lib.ptr(dd), d_raw.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(),
+                              ws.numel(), S()))
+    assert report(tag + " bwd dx", relerr(nchw(d_raw), x.grad), 2e-5)
+    assert report(tag + " bwd dgamma", relerr(dg, gamma.grad), 2e-5)
+    assert report(tag + " bwd dbeta", relerr(db, beta.grad), 2e-5)
+
+
+def test_bn_fold_and_loss_and_adam(report):
+    C = 64
+    g, b, rm, rv, cb = rnd((C,), 90, 0.5, 1.5), rnd((C,), 91), rnd((C,), 92), rnd((C,), 93, 0.5, 1.5), rnd((C,), 94)
+    sc, sh = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    d = [t.to(DEV) for t in (g, b, rm, rv, cb)]
+    _lib.check(L().svs_bn_fold(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(), 1e-5,
+                               sc.data_ptr(), sh.data_ptr(), C, S()))
+    s_want = g.double() / torch.sqrt(rv.double() + 1e-5)
+    assert report("bn_fold scale", relerr(sc, s_want), 1e-6)
+    assert report("bn_fold shift", relerr(sh, b.double() + (cb.double() - rm.double()) * s_want), 1e-6)
+
+    # loss: train.py:274-283 with nn.L1Loss
+    n = 4 * 512 * 128
+    mix_np, voc_np = synth.tiles(4)
+    mix, voc = torch.from_numpy(mix_np).double(), torch.from_numpy(voc_np).double()
+    logit = (rnd((4, 1, 512, 128), 95) * 3).double().requires_grad_(True)
+    mask = torch.sigmoid(logit)
+    loss = (mask * mix - voc).abs().mean() + ((1 - mask) * mix - torch.clamp(mix - voc, min=0)).abs().mean()
+    (loss * 166.66).backward()
+    md = mask.detach().float().to(DEV)
+    dl = torch.empty(n, device=DEV)
+    lo = torch.empty(1, device=DEV)
+    ws = ws_tensor(L().svs_l1_mask_loss_workspace_bytes(n))
+    _lib.check(L().svs_l1_mask_loss_fwd_bwd(md.data_ptr(), torch.from_numpy(mix_np).to(DEV).data_ptr(),
+                                            torch.from_numpy(voc_np).to(DEV).data_ptr(), n, 166.66, dl.data_ptr(), lo.data_ptr(),
+                                            ws.data_ptr(), ws.numel(), S()))
+    assert report("l1_loss value", abs(lo.item() - loss.item()) / loss.item(), 1e-6)
+    assert report("l1_loss d_logit", relerr(dl.view_as(logit), logit.grad), 1e-4)
+
+    # Adam: three steps against torch.optim.Adam
+    n = 10007
+    p0, gs = rnd((n,), 96), [rnd((n,), 97 + i, -0.01, 0.01) for i in range(3)]
+    pt = p0.clone().double().requires_grad_(True)
+    opt = torch.optim.Adam([pt], lr=1e-3)
+    pd, m, v = p0.to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for i, g in enumerate(gs):
+        pt.grad = g.double()
+        opt.step()
+        gd = g.to(DEV)
+        _lib.check(L().svs_adam_step(pd.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), n, 1e-3, 0.9, 0.999, 1e-8, i + 1, 1.0, S()))
+    assert report("adam param", (pd.cpu().double() - pt.detach()).abs().max().item(), 1e-6)
+    assert report("adam exp_avg", relerr(m, opt.state[pt]["exp_avg"]), 1e-5)
+    assert report("adam exp_avg_sq", relerr(v, opt.state[pt]["exp_avg_sq"]), 1e-5)
+
+
+def test_synth_matches_host(report):
+    n = 100003
+    out = torch.empty(n, device=DEV)
+    _lib.check(L().svs_fill_uniform(out.data_ptr(), n, 7, (5 << 32) + 11, 2.0, -1.0, S()))
+    want = synth.uniform(7, n, (5 << 32) + 11) * np.float32(2.0) - np.float32(1.0)
+    assert np.array_equal(out.cpu().numpy(), want)
+    mix, voc = torch.empty((3, 1, 64, 32), device=DEV), torch.empty((3, 1, 64, 32), device=DEV)
+    _lib.check(L().svs_fill_tiles(mix.data_ptr(), voc.data_ptr(), 3, 64, 32, 9, S()))
+    m_np, v_np = synth.tiles(3, 64, 32, first_tile=9)
+    assert np.array_equal(mix.cpu().numpy(), m_np) and np.array_equal(voc.cpu().numpy(), v_np)
+    masks = synth.dropout_masks(6, seed=99, step=3, rank=2)
+    for layer, mk in enumerate(masks):
+        out = torch.empty(mk.shape, device=DEV)
+        _lib.check(L().svs_dropout_mask(out.data_ptr(), mk.shape[0], mk.shape[1], layer, 99, 3, 2, S()))
+        assert np.array_equal(out.cpu().numpy(), mk)
+
+
+def test_stft_istft(report):
+    from oracle import stft_oracle as so
+    for n in (20000, 97536, 100000):
+        y = synth.audio(n)
+        yd = torch.from_numpy(y).to(DEV)
+        T = L().svs_stft_frames(n, 768)
+        assert T == 1 + n // 768
+        mag = torch.empty((513, T), device=DEV)
+        ph = torch.empty((513, T, 2), device=DEV)
+        _lib.check(L().svs_stft_fwd(yd.data_ptr(), n, 1024, 768, mag.data_ptr(), ph.data_ptr(), S()))
+        d = torch.stft(torch.from_numpy(y).double(), 1024, 768, 1024, torch.hann_window(1024, dtype=torch.float64), center=True,
+                       pad_mode="constant", return_complex=True)
+        assert d.shape == (513, T)
+        scale = d.abs().max().item()
+        e = (mag.cpu().double() - d.abs()).abs().max().item() / scale
+        assert report(f"stft mag n={n} vs torch.stft", e, 2e-6)
+        got_c = torch.view_as_complex(ph.cpu().double()) * mag.cpu().double()
+        assert report(f"stft complex n={n} vs torch.stft", (got_c - d).abs().max().item() / scale, 2e-6)
+        m_o, p_o = so.magphase(so.stft(y))
+        assert report(f"stft mag n={n} vs oracle", np.abs(mag.cpu().numpy() - m_o).max() / scale, 2e-6)
+        # inverse, unit-phasor form (data.py:159)
+        ws = ws_tensor(L().svs_istft_workspace_bytes(1024, 768, T))
+        out = torch.empty(768 * (T - 1), device=DEV)
+        _lib.check(L().svs_istft(mag.data_ptr(), ph.data_ptr(), 0, 1024, 768, T, out.data_ptr(), ws.data_ptr(), ws.numel(), S()))
+        want = so.istft(m_o * p_o)
+        interior = slice(1024, -1024)
+        e = np.abs(out.cpu().numpy() - want)[interior].max()
+        assert report(f"istft n={n} vs oracle (interior)", e, 2e-5)
+        # round trip: interior samples come back (hop 768 envelope min 0.043 amplifies fp32 noise ~23x)
+        L_ = 768 * (T - 1)
+        e = np.abs(out.cpu().numpy()[interior] - y[:L_][interior]).max()
+        assert report(f"stft->istft round trip n={n}", e, 5e-5)
+    # angle form against torch.istft with the arguments of train.py:51-58
+    T = 128
+    mag = torch.from_numpy(synth.uniform(3, 513 * T).reshape(513, T))
+    mag[0] = 0
+    ang = torch.from_numpy((synth.uniform(4, 513 * T) * 2 * np.pi - np.pi).astype(np.float32).reshape(513, T))
+    ang[0] = 0
+    want = torch.istft(torch.polar(mag.double(), ang.double()), n_fft=1024, hop_length=768, win_length=1024,
+                       window=torch.hann_window(1024, dtype=torch.float64), return_complex=False)
+    md, ad = mag.to(DEV), ang.to(DEV)
+    ws = ws_tensor(L().svs_istft_workspace_bytes(1024, 768, T))
+    out = torch.empty(768 * (T - 1), device=DEV)
+    _lib.check(L().svs_istft(md.data_ptr(), ad.data_ptr(), 1, 1024, 768, T, out.data_ptr(), ws.data_ptr(), ws.numel(), S()))
+    e = (out.cpu().double() - want).abs()[1024:-1024].max().item() / want.abs().max().item()
+    assert report("istft angle form vs torch.istft (train.py:51-58)", e, 2e-5)
+    # peak normalise (data.py:162-164)
+    pk = torch.empty(1, device=DEV)
+    _lib.check(L().svs_absmax(out.data_ptr(), out.numel(), pk.data_ptr(), ws.data_ptr(), ws.numel(), S()))
+    assert abs(pk.item() - out.abs().max().item()) == 0
+    o2 = out.clone()
+    _lib.check(L().svs_scale_by_inv(o2.data_ptr(), o2.numel(), pk.data_ptr(), 0.9, S()))
+    assert report("peak normalise", (o2 - out / out.abs().max() * 0.9).abs().max().item(), 1e-6)

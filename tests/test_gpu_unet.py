@@ -1,0 +1,240 @@
+"""Whole-network parity (-m gpu): the HIP U-Net behind `UNet` against (a) the golden fixtures captured
+from the imported reference (tests/golden, oracle/gen_golden.py) and (b) the CPU oracle run live on
+the same seeded inputs.  Gates: eval mask mean-absolute error <= 1e-4 (we also bound the
+max); tile bookkeeping bit-exact; train-step loss rel err <= 1e-5; gradients within the fp32 noise
+scale that the reference itself shows against its own fp64 run."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import unet_oracle as uo
+from svs_unet_pytorch_amd import _lib, synth
+from svs_unet_pytorch_amd.inference import segment_plan, separate
+from svs_unet_pytorch_amd.model import DEC_IO, UNet
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def make_model(trained_stats=True):
+    m = UNet()
+    sd = {k: torch.from_numpy(np.array(v)) for k, v in synth.closed_form_state(trained_stats=trained_stats).items()}
+    m.load_state_dict(sd, strict=True)
+    return m.to(DEV)
+
+
+def ws_view(model, kind, name, B, H, W, shape):
+    off = _lib.lib().svs_unet_ws_offset(name.encode(), B, H, W, 1 if kind == "train" else 0)
+    assert off >= 0, name
+    ws = model._ws[(kind, B, H, W)]
+    n = int(np.prod(shape))
+    return ws[off:off + 4 * n].view(torch.float32).view(shape)
+
+
+def test_eval_forward_golden(golden, report):
+    g = golden("eval_forward.npz")
+    model = make_model().eval()
+    mix16, _ = synth.tiles(16)
+    x = torch.from_numpy(mix16).to(DEV)
+    with torch.no_grad():
+        m1 = model(x[:1]).cpu()
+        m16 = model(x).cpu()
+    want = torch.from_numpy(g["mask_tile0"])
+    assert report("eval mask tile0 L1 vs reference", (m1[0, 0] - want).abs().mean().item(), 1e-4)
+    assert report("eval mask tile0 max vs reference", (m1[0, 0] - want).abs().max().item(), 1e-4)
+    assert report("eval mask16 per-tile sums", np.abs(m16.double().sum((1, 2, 3)).numpy() - g["mask16_sum"]).max() / 65536, 1e-5)
+    assert report("eval mask16 corners", np.abs(m16[:, 0, :8, :8].numpy() - g["mask16_corner"]).max(), 1e-4)
+    assert report("eval batch independence", (m1[0] - m16[0]).abs().max().item(), 0.0)
+    # per-layer intermediates of tile 0 against the reference's hooks (sample + stats)
+    with torch.no_grad():
+        model(x[:1])
+    B, H, W = 1, 512, 128
+    hw = [(512, 128)]
+    for _ in range(6):
+        hw.append(((hw[-1][0] + 1) // 2, (hw[-1][1] + 1) // 2))
+    ch = (1, 16, 32, 64, 128, 256, 512)
+    for k in range(1, 7):
+        h, w = hw[k]
+        if k == 6:
+            t = ws_view(model, "eval", "c6", B, H, W, (B, h, w, 512))
+        else:
+            t = ws_view(model, "eval", f"cat{k}", B, H, W, (B, h, w, 2 * ch[k]))[..., ch[k]:]
+        nchw = t.permute(0, 3, 1, 2).contiguous().cpu()
+        key = f"tap.conv{k}.out"
+        assert tuple(g[key + ".shape"]) == tuple(nchw.shape)
+        f = nchw.reshape(-1)
+        step = max(f.numel() // 256, 1)
+        scale = max(abs(g[key + ".stats"][2]), abs(g[key + ".stats"][3]))
+        assert report(f"eval {key} sample", np.abs(f[::step][:256].numpy() - g[key + ".sample"]).max() / scale, 2e-5)
+        assert report(f"eval {key} abs-sum", abs(nchw.double().abs().sum().item() - g[key + ".stats"][1]) / g[key + ".stats"][1], 1e-5)
+    for j in range(1, 6):
+        h, w = hw[6 - j]
+        n = DEC_IO[j - 1][1]
+        t = ws_view(model, "eval", f"cat{6 - j}", B, H, W, (B, h, w, 2 * n))[..., :n]
+        nchw = t.permute(0, 3, 1, 2).contiguous().cpu()
+        key = f"tap.deconv{j}.out"
+        assert tuple(g[key + ".shape"]) == tuple(nchw.shape)
+        f = nchw.reshape(-1)
+        step = max(f.numel() // 256, 1)
+        scale = max(abs(g[key + ".stats"][2]), abs(g[key + ".stats"][3]))
+        assert report(f"eval {key} sample", np.abs(f[::step][:256].numpy() - g[key + ".sample"]).max() / scale, 2e-5)
+
+
+def test_eval_forward_odd_sizes(golden, report):
+    g = golden("eval_odd_sizes.npz")
+    model = make_model().eval()
+    for (h, w) in ((513, 128), (512, 100), (512, 32), (64, 16)):
+        x = torch.from_numpy(synth.uniform(synth.SEED_MIX, h * w, 7 << 32).reshape(1, 1, h, w)).to(DEV)
+        with torch.no_grad():
+            y = model(x).cpu()
+        assert y.shape == (1, 1, h, w)
+        assert report(f"eval mask {h}x{w} vs reference", np.abs(y[0, 0].numpy() - g[f"mask_{h}x{w}"]).max(), 1e-4)
+
+
+def test_eval_forward_vs_oracle_live(report):
+    model = make_model().eval()
+    st = uo.to_torch_state(synth.closed_form_state())
+    mix, _ = synth.tiles(3, first_tile=40)
+    with torch.no_grad():
+        want = uo.forward(st, torch.from_numpy(mix))
+        got = model(torch.from_numpy(mix).to(DEV)).cpu()
+    assert report("eval mask B=3 L1 vs oracle", (got - want).abs().mean().item(), 1e-4)
+    assert report("eval mask B=3 max vs oracle", (got - want).abs().max().item(), 1e-4)
+
+
+def test_inference_tiling_golden(golden, report):
+    g = golden("inference_tiling.npz")
+    assert segment_plan(1) == [(0, 1, 127)]
+    assert segment_plan(128) == [(0, 128, 0)]
+    assert segment_plan(300) == [(0, 128, 0), (128, 256, 0), (256, 300, 84)]
+    model = make_model().eval()
+    for n, T in enumerate(g["lengths"]):
+        T = int(T)
+        spec = synth.uniform(synth.SEED_MIX, 513 * T, (200 + n) << 32).reshape(513, T)
+        for solo in (1, 0):
+            key = f"solo{solo}.T{T}"
+            if key not in g.files:
+                continue
+            got = separate(model, spec, 128, bool(solo))
+            assert got.shape == (513, T) and got.dtype == np.float32
+            assert np.all(got[0] == 0)
+            assert report(f"inference {key} vs reference inference.py", np.abs(got - g[key]).max(), 1e-4)
+
+
+def _grads_by_name(model):
+    return {n: p.grad.detach().cpu().double() for n, p in model.named_parameters()}
+
+
+@pytest.mark.parametrize("tag", ["nodrop", "drop"])
+def test_train_steps_golden(tag, golden, report):
+    g = golden("train_steps.npz")
+    names = list(g[tag + ".param_names"])
+    B = 4
+    mix4, voc4 = synth.tiles(B, first_tile=100)
+    mix, voc = torch.from_numpy(mix4).to(DEV), torch.from_numpy(voc4).to(DEV)
+    model = make_model(trained_stats=False).train()
+    assert [n for n, _ in model.named_parameters()] == names
+    for step in range(2):
+        masks = [torch.from_numpy(m) for m in synth.dropout_masks(B, seed=99, step=step)] if tag == "drop" else []
+        model.set_dropout_masks(masks)
+        model.optim.zero_grad()
+        loss = model.fwd_bwd(mix, voc)
+        p = f"{tag}.f64.step{step}."
+        q = f"{tag}.f32.step{step}."
+        want_loss = float(g[p + "loss"])
+        assert report(f"train {tag} step{step} loss", abs(loss.item() - want_loss) / want_loss, 1e-5)
+        grads = _grads_by_name(model)
+        gn64, gn32 = g[p + "grad_norm"], g[q + "grad_norm"]
+        for i, n in enumerate(names):
+            got = grads[n].norm().item()
+            # fp32 noise scale: what the reference's own fp32 run deviates from its fp64 run, floored
+            noise = max(abs(gn32[i] - gn64[i]), 1e-4 * gn64[i], 2e-6)
+            assert report(f"train {tag} step{step} |grad| {n}", abs(got - gn64[i]) / noise, 20.0), (n, got, gn64[i], gn32[i])
+        for n in ("conv1.0.weight", "conv4.0.weight", "deconv6.weight", "deconv3.weight", "conv2.1.weight",
+                  "deconv2_BAD.0.bias", "conv6.1.bias", "deconv6.bias"):
+            f = grads[n].reshape(-1)
+            stp = max(f.numel() // 128, 1)
+            got = f[::stp][:128].numpy()
+            w64, w32 = g[p + "grad_sample." + n].astype(np.float64), g[q + "grad_sample." + n].astype(np.float64)
+            noise = max(np.abs(w32 - w64).max(), 1e-4 * np.abs(w64).max(), 1e-9)
+            assert report(f"train {tag} step{step} grad sample {n}", np.abs(got - w64).max() / noise, 20.0)
+        model.optim.step()
+        sd = model.state_dict()
+        for k in sd:
+            if "running_" in k:
+                want = g[p + "buf." + k]
+                assert report(f"train {tag} step{step} {k}", np.abs(sd[k].cpu().numpy() - want).max() / max(np.abs(want).max(), 1e-3), 2e-4)
+            if "num_batches_tracked" in k:
+                assert int(sd[k]) == step + 1
+
+
+def test_train_vs_oracle_live_and_autograd_path(report):
+    """fp64 oracle on the box's CPU, full per-parameter gradient comparison; then the autograd path
+    (model(mix) + torch loss + .backward(), the shape of train.py:274-299) against the fused path."""
+    B = 2
+    mix_np, voc_np = synth.tiles(B, first_tile=300)
+    fresh = synth.closed_form_state(trained_stats=False)
+    masks_np = synth.dropout_masks(B, seed=7, step=0)
+    st = uo.to_torch_state(fresh, torch.float64)
+    opt = uo.new_adam_state(st)
+    lo, grads_o = uo.train_step(st, opt, torch.from_numpy(mix_np).double(), torch.from_numpy(voc_np).double(),
+                                dropout_masks=[torch.from_numpy(m).double() for m in masks_np], loss_scale=166.66, apply_update=False)
+    mix, voc = torch.from_numpy(mix_np).to(DEV), torch.from_numpy(voc_np).to(DEV)
+    model = make_model(trained_stats=False).train()
+    model.set_dropout_masks([torch.from_numpy(m) for m in masks_np])
+    model.optim.zero_grad()
+    loss = model.fwd_bwd(mix, voc, loss_scale=166.66)
+    assert report("train live loss vs fp64 oracle", abs(loss.item() - lo) / lo, 1e-5)
+    fused = _grads_by_name(model)
+    for n, gw in grads_o.items():
+        if n.endswith(".0.bias") and n.startswith("conv") or (n.startswith("deconv") and n.endswith(".bias") and "BAD" not in n and n != "deconv6.bias"):
+            # bias feeding a BatchNorm: true gradient is exactly 0, what is left is rounding noise
+            assert report(f"train live grad {n} (zero)", fused[n].abs().max().item(), 1e-3)
+            continue
+        e = (fused[n] - gw).norm().item() / max(gw.norm().item(), 1e-12)
+        assert report(f"train live grad {n} rel-L2", e, 2e-2)
+    # autograd path
+    model2 = make_model(trained_stats=False).train()
+    model2.set_dropout_masks([torch.from_numpy(m) for m in masks_np])
+    model2.optim.zero_grad()
+    mask = model2(mix)
+    pred_vocal = mask * mix
+    pred_accomp = (1 - mask) * mix
+    target_accomp = torch.clamp(mix - voc, min=0.0)
+    l1 = model2.crit(pred_vocal, voc) + model2.crit(pred_accomp, target_accomp)
+    (166.66 * l1).backward()
+    assert report("autograd path loss", abs(l1.item() - loss.item()) / loss.item(), 1e-6)
+    auto = _grads_by_name(model2)
+    for n in fused:
+        d = (auto[n] - fused[n]).norm().item()
+        assert report(f"autograd path grad {n}", d / max(fused[n].norm().item(), 1e-6), 1e-3)
+    # accumulation semantics: a second backward without zero_grad doubles the gradient
+    mask = model2(mix)
+    l1 = model2.crit(mask * mix, voc) + model2.crit((1 - mask) * mix, torch.clamp(mix - voc, min=0.0))
+    (166.66 * l1).backward()
+    twice = _grads_by_name(model2)
+    n = "deconv3.weight"
+    assert report("gradient accumulation", (twice[n] - 2 * auto[n]).norm().item() / auto[n].norm().item(), 1e-3)
+
+
+def test_train_step_learns_and_checkpoint_roundtrip(tmp_path, report):
+    B = 8
+    mix_np, voc_np = synth.tiles(B, first_tile=500)
+    mix, voc = torch.from_numpy(mix_np).to(DEV), torch.from_numpy(voc_np).to(DEV)
+    model = make_model(trained_stats=False).train()
+    losses = [model.train_step(mix, voc, loss_scale=166.66).item() for _ in range(12)]
+    assert all(np.isfinite(losses))
+    assert losses[-1] < losses[0], losses
+    path = str(tmp_path / "svs_test.pth")
+    model.save(path)
+    m2 = UNet().to(DEV)
+    m2.load(path)
+    for (k, a), (_, b) in zip(model.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a.cpu(), b.cpu()), k
+    assert m2.optim._step == model.optim._step == 12
+    assert torch.equal(m2.optim._m.cpu(), model.optim._m.cpu())
+    model.eval(), m2.eval()
+    with torch.no_grad():
+        assert torch.equal(model(mix[:2]).cpu(), m2(mix[:2]).cpu())
