@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Headline benchmark: spectrogram tiles/sec (512x128) of the U-Net training step (fwd + L1 loss + bwd +
+gradient all-reduce + Adam) on N GPUs of one node, one process per GPU (BASELINE.json `metric`).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode train|eval] [--batch B_per_gpu]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload: BASELINE.json configs[2] at N=1 (train.py L1-loss step, batch 64 on one MI355X) and configs[3] at
+N=8 (64 tiles per GPU = global batch 512, RCCL gradient all-reduce): weak scaling.  `--mode eval --batch 16`
+is configs[1] (eval forward).  Inputs are synthetic tiles (svs_fill_tiles) already resident in HBM.
+
+One JSON line on rank 0 with `roofline` (the dominant kernel timed live with HIP events on the stream it is
+launched on, against the fp32 MFMA peak) and `cpu_baseline` (the CPU oracle -- the plain-torch restatement of
+the reference -- timed on this box's host cores on a bounded sample).  The oracle is used ONLY there.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from svs_unet_pytorch_amd import _lib, synth  # noqa: E402
+from svs_unet_pytorch_amd.model import ALPHA_L1, DEC_IO, ENC_CHANNELS, UNet  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+FWD_GFLOP_PER_TILE = 1.507328
+TRAIN_GFLOP_PER_TILE = 4.5088768
+
+
+def layer_table(B, H=512, W=128):
+    """(name, kind, geometry, algorithmic GFLOP) of every MFMA layer of one forward at batch B."""
+    hw = [(H, W)]
+    for _ in range(6):
+        hw.append(((hw[-1][0] + 1) // 2, (hw[-1][1] + 1) // 2))
+    rows = []
+    for k in range(2, 7):
+        (h, w), (ho, wo) = hw[k - 1], hw[k]
+        c, n = ENC_CHANNELS[k - 1], ENC_CHANNELS[k]
+        rows.append((f"conv{k}", "enc", (B, h, w, c, n, ho, wo), 2.0 * B * ho * wo * n * c * 25 / 1e9))
+    for j in range(5):
+        (h, w), (ho, wo) = hw[6 - j], hw[5 - j]
+        c, n = DEC_IO[j]
+        rows.append((f"deconv{j + 1}", "dec", (B, h, w, c, n, ho, wo), 2.0 * B * h * w * n * c * 25 / 1e9))
+    return rows
+
+
+def time_layers(B, reps=10):
+    """Per-layer forward kernels timed with HIP events on torch's current stream (the stream every launch of
+    the library is given).  Returns [(name, kernel family, ms, GFLOP)]."""
+    L = _lib.lib()
+    dev = "cuda"
+    out = []
+    for name, kind, (b, h, w, c, n, ho, wo), gflop in layer_table(B):
+        x = torch.rand((b, h, w, c), device=dev)
+        wp = (torch.rand(n * c * 25, device=dev) - 0.5) * 0.05
+        sc, sh = torch.rand(n, device=dev) + 0.5, torch.rand(n, device=dev) - 0.5
+        y = torch.empty((b, ho, wo, n), device=dev)
+        if kind == "enc":
+            ws = torch.empty(int(L.svs_enc_block_workspace_bytes(b, h, w, c, n)) + 4096, dtype=torch.uint8, device=dev)
+            run = lambda: L.svs_enc_block_fwd(x.data_ptr(), c, b, h, w, c, wp.data_ptr(), None, sc.data_ptr(), sh.data_ptr(),
+                                              0.2, y.data_ptr(), n, n, 0, ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+        else:
+            ws = torch.empty(int(L.svs_dec_block_workspace_bytes(b, h, w, c, ho, wo, n)) + 4096, dtype=torch.uint8, device=dev)
+            run = lambda: L.svs_dec_block_fwd(x.data_ptr(), c, b, h, w, c, wp.data_ptr(), None, sc.data_ptr(), sh.data_ptr(),
+                                              0.0, y.data_ptr(), n, ho, wo, n, 0, ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+        for _ in range(3):
+            _lib.check(run(), name)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        out.append((name, "conv_gemm_kernel<GATHER>" if kind == "enc" else "conv_gemm_kernel<PARITY>", e0.elapsed_time(e1) / reps, gflop))
+    return out
+
+
+def cpu_baseline(mode, seconds_budget=20.0):
+    """The CPU oracle (oracle/unet_oracle.py) on this box's host cores: same synthetic tiles, fp32."""
+    from oracle import unet_oracle as uo
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    B = 16
+    mix_np, voc_np = synth.tiles(B)
+    mix, voc = torch.from_numpy(mix_np), torch.from_numpy(voc_np)
+    st = uo.to_torch_state(synth.closed_form_state(trained_stats=False))
+    if mode == "train":
+        opt = uo.new_adam_state(st)
+        masks = [torch.from_numpy(m) for m in synth.dropout_masks(B, seed=1)]
+        step = lambda: uo.train_step(st, opt, mix, voc, dropout_masks=masks, loss_scale=ALPHA_L1)
+    else:
+        def step():
+            with torch.no_grad():
+                uo.forward(st, mix, training=False)
+    for _ in range(2):
+        step()
+    t0 = time.perf_counter()
+    it = 0
+    while True:
+        step()
+        it += 1
+        el = time.perf_counter() - t0
+        if it >= 5 and (el > seconds_budget or it >= 40):
+            break
+    return {"value": round(B * it / el, 2), "unit": "tiles/s", "cores": cores, "kind": "port",
+            "sample": f"{it} {'L1 train steps (fwd+bwd+Adam)' if mode == 'train' else 'eval forwards'} of batch {B}, "
+                      f"fp32 torch CPU oracle, {cores} threads, {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--mode", choices=("train", "eval"), default="train")
+    ap.add_argument("--batch", type=int, default=0, help="tiles per GPU (default 64 train / 16 eval)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-layers", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    B = args.batch or (64 if args.mode == "train" else 16)
+    H, W = 512, 128
+    model = UNet()
+    model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in synth.closed_form_state(trained_stats=False).items()})
+    model.to(dev)
+    model.rank = rank
+    mix = torch.empty((B, 1, H, W), device=dev)
+    voc = torch.empty_like(mix)
+    _lib.check(_lib.lib().svs_fill_tiles(mix.data_ptr(), voc.data_ptr(), B, H, W, rank * B, _lib.stream_ptr()), "svs_fill_tiles")
+
+    grad_sync = None
+    if args.mode == "train":
+        model.train()
+        if world > 1:
+            from svs_unet_pytorch_amd.parallel import GradAllReduce
+            grad_sync = GradAllReduce(model, dist.group.WORLD)
+        step = lambda: model.train_step(mix, voc, loss_scale=ALPHA_L1, grad_sync=grad_sync)
+    else:
+        model.eval()
+
+        def step():
+            with torch.no_grad():
+                return model(mix)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        tiles_per_s = world * B * args.steps / elapsed
+        gflop = TRAIN_GFLOP_PER_TILE if args.mode == "train" else FWD_GFLOP_PER_TILE
+        res = {
+            "metric": "spectrogram-tiles/sec (512x128) U-Net " + ("fwd+bwd (L1 train step incl. Adam" + (", RCCL grad all-reduce)" if world > 1 else ")") if args.mode == "train" else "eval forward"),
+            "value": round(tiles_per_s, 1), "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("train.py L1-loss step, 512x128 tiles, batch %d per GPU" % B) if args.mode == "train"
+                       else ("U-Net eval forward, 512x128 tiles, batch %d per GPU" % B),
+                       "global_batch": B * world, "parallelism": f"dp{world}", "mode": args.mode},
+            "conv_roofline_frac": round(tiles_per_s / world * gflop / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4),
+        }
+        if world == 1:
+            if not args.no_layers:
+                layers = time_layers(B)
+                fam = {}
+                for name, family, ms, gf in layers:
+                    a = fam.setdefault(family, [0.0, 0.0, 0])
+                    a[0] += ms; a[1] += gf; a[2] += 1
+                dom = max(fam, key=lambda f: fam[f][0])
+                ms, gf, cnt = fam[dom]
+                ach = gf / ms            # GFLOP / ms = TFLOP/s
+                res["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
+                                   "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                                   "launches": cnt, "avg_launch_ms": round(ms / cnt, 4),
+                                   "algorithmic_gflop_per_launch": round(gf / cnt, 3)}
+                res["layers"] = {name: {"ms": round(ms, 4), "tflops": round(gf / ms, 2)} for name, _, ms, gf in layers}
+            if not args.no_cpu_baseline:
+                res["cpu_baseline"] = cpu_baseline(args.mode)
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

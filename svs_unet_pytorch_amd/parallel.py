@@ -1,0 +1,45 @@
+"""Data parallelism over the GPUs of one node: one process per GPU, tiles sharded over the batch
+(tiles are independent; the training step has exactly one exchange, the gradient sum).
+
+The reference is single-process (it has no distributed code at all), so the semantics are chosen here:
+  * gradients: ONE all-reduce (SUM, fp32) of the model's flat 9,823,313-element gradient buffer per step
+    over RCCL/xGMI (`backend="nccl"` is RCCL on ROCm); the 1/world mean is folded into the fused Adam
+    kernel (`FusedAdam.grad_scale`), so no extra pass over the gradients;
+  * BatchNorm: per-GPU batch statistics (what DistributedDataParallel over the reference would do);
+    running statistics stay per rank and rank 0's are the ones checkpointed;
+  * Dropout2d: the rank is folded into the mask counter, so shards draw independent masks;
+  * parameters: identical on every rank after `broadcast_parameters`, and they stay identical because
+    every rank applies the same Adam update to the same summed gradient.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items: int, rank: int, world: int):
+    """[begin, end) of the contiguous share of `n_items` units owned by `rank` (sizes differ by <= 1)."""
+    base, rem = divmod(n_items, world)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+class GradAllReduce:
+    """`grad_sync` hook for `UNet.train_step`: sums the flat gradient buffer across the group."""
+
+    def __init__(self, model, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        model.optim.grad_scale = 1.0 / self.world
+        model.rank = dist.get_rank(group)
+
+    def __call__(self, flat_grad: torch.Tensor):
+        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+
+
+def broadcast_parameters(model, src: int = 0, group=None):
+    """Make every rank start from rank `src`'s parameters and BatchNorm buffers."""
+    dist.broadcast(model._flat, src=src, group=group)
+    dist.broadcast(model._bn_flat, src=src, group=group)
+    dist.broadcast(model._nbt_flat, src=src, group=group)
+    model._param_epoch += 1

@@ -356,8 +356,8 @@ def test_bn_fold_and_loss_and_adam(report):
     dl = torch.empty(n, device=DEV)
     lo = torch.empty(1, device=DEV)
     ws = ws_tensor(L().svs_l1_mask_loss_workspace_bytes(n))
-    _lib.check(L().svs_l1_mask_loss_fwd_bwd(md.data_ptr(), torch.from_numpy(mix_np).to(DEV).data_ptr(),
-                                            torch.from_numpy(voc_np).to(DEV).data_ptr(), n, 166.66, dl.data_ptr(), lo.data_ptr(),
+    mixd, vocd = torch.from_numpy(mix_np).to(DEV), torch.from_numpy(voc_np).to(DEV)
+    _lib.check(L().svs_l1_mask_loss_fwd_bwd(md.data_ptr(), mixd.data_ptr(), vocd.data_ptr(), n, 166.66, dl.data_ptr(), lo.data_ptr(),
                                             ws.data_ptr(), ws.numel(), S()))
     assert report("l1_loss value", abs(lo.item() - loss.item()) / loss.item(), 1e-6)
     assert report("l1_loss d_logit", relerr(dl.view_as(logit), logit.grad), 1e-4)

@@ -46,7 +46,8 @@ def test_eval_forward_golden(golden, report):
     assert report("eval mask tile0 max vs reference", (m1[0, 0] - want).abs().max().item(), 1e-4)
     assert report("eval mask16 per-tile sums", np.abs(m16.double().sum((1, 2, 3)).numpy() - g["mask16_sum"]).max() / 65536, 1e-5)
     assert report("eval mask16 corners", np.abs(m16[:, 0, :8, :8].numpy() - g["mask16_corner"]).max(), 1e-4)
-    assert report("eval batch independence", (m1[0] - m16[0]).abs().max().item(), 0.0)
+    # B=1 and B=16 pick different tile / split-K plans, so the summation order differs: not bit-equal
+    assert report("eval batch independence", (m1[0] - m16[0]).abs().max().item(), 1e-6)
     # per-layer intermediates of tile 0 against the reference's hooks (sample + stats)
     with torch.no_grad():
         model(x[:1])
@@ -165,7 +166,11 @@ def test_train_steps_golden(tag, golden, report):
         for k in sd:
             if "running_" in k:
                 want = g[p + "buf." + k]
-                assert report(f"train {tag} step{step} {k}", np.abs(sd[k].cpu().numpy() - want).max() / max(np.abs(want).max(), 1e-3), 2e-4)
+                # step 0 is before any update: tight.  Afterwards Adam has turned the rounding noise of the
+                # exactly-zero pre-BN bias gradients into +-lr-sized bias moves (any fp32 run does), which
+                # shifts the running means by up to momentum*lr.
+                tol = 1e-5 if step == 0 else 5e-3
+                assert report(f"train {tag} step{step} {k}", np.abs(sd[k].cpu().numpy() - want).max() / max(np.abs(want).max(), 1e-3), tol)
             if "num_batches_tracked" in k:
                 assert int(sd[k]) == step + 1
 
