@@ -145,9 +145,10 @@ int svs_l1_mask_loss_fwd_bwd(const float* mask, const float* mix, const float* v
                              float* d_logit, float* loss, void* ws, size_t ws_bytes, hipStream_t stream);
 
 /* torch.optim.Adam(lr, betas, eps), no weight decay / amsgrad (model.py:116), over flat buffers.
- * g is multiplied by grad_scale first (1/world for data-parallel mean). step is 1-based. */
-int svs_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                  float eps, int step, float grad_scale, hipStream_t stream);
+ * g is multiplied by grad_scale first (1/world for data-parallel mean). step is 1-based.  The hyper-parameters
+ * are doubles because torch derives 1-beta and the bias corrections in double before rounding to fp32. */
+int svs_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
+                  double eps, int step, float grad_scale, hipStream_t stream);
 
 /* inference.py:100-107: out = mix * mask, or mix * (1 - mask) when invert != 0. */
 int svs_apply_mask(const float* mix, const float* mask, float* out, int64_t n, int invert, hipStream_t stream);

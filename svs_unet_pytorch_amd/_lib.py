@@ -19,6 +19,7 @@ P = C.c_void_p
 I = C.c_int
 L = C.c_int64
 F = C.c_float
+D = C.c_double
 Z = C.c_size_t
 U32 = C.c_uint32
 U64 = C.c_uint64
@@ -50,7 +51,7 @@ _SIGS = {
     "svs_bn_bwd": (I, [P, L, P, L, L, I, L, P, P, P, P, F, P, P, P, P, P, Z, P]),
     "svs_l1_mask_loss_workspace_bytes": (Z, [L]),
     "svs_l1_mask_loss_fwd_bwd": (I, [P, P, P, L, F, P, P, P, Z, P]),
-    "svs_adam_step": (I, [P, P, P, P, L, F, F, F, F, I, F, P]),
+    "svs_adam_step": (I, [P, P, P, P, L, D, D, D, D, I, F, P]),
     "svs_apply_mask": (I, [P, P, P, L, I, P]),
     "svs_unet_param_offset": (L, [I]),
     "svs_unet_buffer_offset": (L, [I, I]),
@@ -90,6 +91,10 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise SvsError(f"{LIB_PATH} not found: build it with `python -m svs_unet_pytorch_amd.build` "
                            "(there is no CPU or PyTorch fallback for the HIP path)")
+        # torch first: its bundled libamdhip64 must be THE HIP runtime of the process (the streams we are
+        # handed belong to it).  Loaded the other way round, the system runtime and torch's both get
+        # mapped and the second one finds no device.
+        import torch  # noqa: F401
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(handle, name)

@@ -71,17 +71,41 @@ __global__ __launch_bounds__(256) void channel_reduce_kernel(BnCtx p, float* __r
   }
 }
 
-__global__ void bn_finalize_kernel(const float* __restrict__ partial, int nblk, long P, int C, float eps, float momentum,
-                                   float* running_mean, float* running_var, long long* nbt, float* save_mean,
-                                   float* save_invstd) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c == 0 && nbt) nbt[0] += 1;
-  if (c >= C) return;
-  double s = 0.0, ss = 0.0;
-  for (int b = 0; b < nblk; ++b) {
-    s += (double)partial[(long)b * 2 * C + c];
-    ss += (double)partial[(long)b * 2 * C + C + c];
+// Sums the per-workgroup partials ws[blk][2][C] of 4 adjacent channels with one 256-thread block
+// (double accumulation, fixed order: reproducible).  Result: lane k (<4) of wave 0 gets (s, ss) of channel c0+k.
+__device__ __forceinline__ void reduce_partials4(const float* __restrict__ partial, int nblk, int C, int c0, double* s, double* ss) {
+  __shared__ double sh[2][4][4];     // [which][wave][channel]
+  double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+  for (int r = threadIdx.x; r < nblk; r += 256) {
+    const f32x4 x = *(const f32x4*)(partial + (long)r * 2 * C + c0);
+    const f32x4 y = *(const f32x4*)(partial + (long)r * 2 * C + C + c0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { a[k] += (double)x[k]; b[k] += (double)y[k]; }
   }
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a[k] += __shfl_xor(a[k], o, 64); b[k] += __shfl_xor(b[k], o, 64); }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { sh[0][wave][k] = a[k]; sh[1][wave][k] = b[k]; }
+  }
+  __syncthreads();
+  const int k = threadIdx.x & 3;
+  *s = (sh[0][0][k] + sh[0][1][k]) + (sh[0][2][k] + sh[0][3][k]);
+  *ss = (sh[1][0][k] + sh[1][1][k]) + (sh[1][2][k] + sh[1][3][k]);
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int nblk, long P, int C, float eps,
+                                                          float momentum, float* running_mean, float* running_var,
+                                                          long long* nbt, float* save_mean, float* save_invstd) {
+  const int c0 = blockIdx.x * 4;
+  double s, ss;
+  reduce_partials4(partial, nblk, C, c0, &s, &ss);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) nbt[0] += 1;
+  if (threadIdx.x >= 4) return;
+  const int c = c0 + threadIdx.x;
   const double mean = s / (double)P;
   double var = ss / (double)P - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -111,16 +135,14 @@ __global__ __launch_bounds__(256) void bn_act_apply_kernel(BnCtx p, float* __res
 }
 
 // coef[0][c] = gamma*invstd, coef[1][c] = mean(dz), coef[2][c] = mean(dz*xhat)
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, long P, int C,
-                                       const float* __restrict__ gamma, const float* __restrict__ invstd,
-                                       float* dgamma, float* dbeta, float* coef) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, sx = 0.0;
-  for (int b = 0; b < nblk; ++b) {
-    s += (double)partial[(long)b * 2 * C + c];
-    sx += (double)partial[(long)b * 2 * C + C + c];
-  }
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, long P, int C,
+                                                              const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                                              float* dgamma, float* dbeta, float* coef) {
+  const int c0 = blockIdx.x * 4;
+  double s, sx;
+  reduce_partials4(partial, nblk, C, c0, &s, &sx);
+  if (threadIdx.x >= 4) return;
+  const int c = c0 + threadIdx.x;
   if (dbeta) dbeta[c] = (float)s;
   if (dgamma) dgamma[c] = (float)sx;
   coef[c] = gamma[c] * invstd[c];
@@ -182,7 +204,7 @@ extern "C" int svs_bn_finalize(const void* ws, int64_t P, int C, float eps, floa
                                hipStream_t stream) {
   SVS_REQUIRE(ws && save_mean && save_invstd, "svs_bn_finalize: null pointer");
   const int nb = red_blocks(P, C);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, (const float*)ws, nb, (long)P, C, eps,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C / 4), dim3(256), 0, stream, (const float*)ws, nb, (long)P, C, eps,
                      momentum, running_mean, running_var, (long long*)num_batches_tracked, save_mean, save_invstd);
   SVS_CHECK_LAUNCH("bn_finalize");
   return SVS_OK;
@@ -217,7 +239,7 @@ extern "C" int svs_bn_bwd(const float* dy, int64_t lddy, const float* raw, int64
   p.dy = dy; p.lddy = lddy;
   hipLaunchKernelGGL(channel_reduce_kernel<1>, dim3(nb), dim3(256), 0, stream, p, partial, (P + nb - 1) / nb);
   SVS_CHECK_LAUNCH("bn_bwd_reduce");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, (const float*)partial, nb, (long)P, C,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C / 4), dim3(256), 0, stream, (const float*)partial, nb, (long)P, C,
                      gamma, save_invstd, dgamma, dbeta, coef);
   SVS_CHECK_LAUNCH("bn_bwd_finalize");
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(P * (C / 4))), dim3(256), 0, stream, p, (const float*)coef, d_raw);
@@ -228,18 +250,16 @@ extern "C" int svs_bn_bwd(const float* dy, int64_t lddy, const float* raw, int64
 // per-channel sum of a (P, C) view -> out[C]   (bias gradients).  Uses the stats kernel's partials.
 int svs_channel_sum_run(const float* x, long ldx, long P, int C, float* out, void* ws, size_t ws_bytes, hipStream_t stream);
 
-__global__ void channel_sum_finalize_kernel(const float* __restrict__ partial, int nblk, int C, float* out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += (double)partial[(long)b * 2 * C + c];
-  out[c] = (float)s;
+__global__ __launch_bounds__(256) void channel_sum_finalize_kernel(const float* __restrict__ partial, int nblk, int C, float* out) {
+  double s, ss;
+  reduce_partials4(partial, nblk, C, blockIdx.x * 4, &s, &ss);
+  if (threadIdx.x < 4) out[blockIdx.x * 4 + threadIdx.x] = (float)s;
 }
 
 int svs_channel_sum_run(const float* x, long ldx, long P, int C, float* out, void* ws, size_t ws_bytes, hipStream_t stream) {
   int rc = svs_bn_stats(x, ldx, P, C, ws, ws_bytes, stream);
   if (rc) return rc;
-  hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, (const float*)ws, red_blocks(P, C), C, out);
+  hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3(C / 4), dim3(256), 0, stream, (const float*)ws, red_blocks(P, C), C, out);
   SVS_CHECK_LAUNCH("channel_sum_finalize");
   return SVS_OK;
 }
@@ -384,25 +404,26 @@ extern "C" int svs_scale_by_inv(float* x, int64_t n, const float* denom, float n
 // Adam (torch.optim.Adam single-tensor update, model.py:116)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                   float* __restrict__ v, long n, float b1, float b2, float eps,
-                                                   float step_size, float bc2_sqrt, float gscale) {
+                                                   float* __restrict__ v, long n, float b1, float b2, float omb1,
+                                                   float omb2, float eps, float step_size, float bc2_sqrt, float gscale) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const float gi = g[i] * gscale;
-    const float mi = m[i] * b1 + (1.f - b1) * gi;
-    const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+    const float mi = m[i] * b1 + omb1 * gi;
+    const float vi = v[i] * b2 + omb2 * gi * gi;
     m[i] = mi;
     v[i] = vi;
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
     p[i] -= step_size * (mi / denom);
   }
 }
-extern "C" int svs_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                             float eps, int step, float grad_scale, hipStream_t stream) {
+extern "C" int svs_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
+                             double eps, int step, float grad_scale, hipStream_t stream) {
   SVS_REQUIRE(p && g && m && v && n > 0 && step >= 1, "svs_adam_step: bad arguments");
-  const double bc1 = 1.0 - pow((double)beta1, step);
-  const double bc2 = 1.0 - pow((double)beta2, step);
-  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, stream, p, g, m, v, (long)n, beta1, beta2, eps,
-                     (float)((double)lr / bc1), (float)sqrt(bc2), grad_scale);
+  const double bc1 = 1.0 - pow(beta1, step);
+  const double bc2 = 1.0 - pow(beta2, step);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, stream, p, g, m, v, (long)n, (float)beta1,
+                     (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)(lr / bc1), (float)sqrt(bc2),
+                     grad_scale);
   SVS_CHECK_LAUNCH("adam");
   return SVS_OK;
 }

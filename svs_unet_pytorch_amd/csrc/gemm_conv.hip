@@ -18,6 +18,8 @@
 // the B side, so the K order inside a tile is permuted consistently and no shuffles are needed.
 //
 // Bound: MFMA (fp32 157.3 TFLOP/s peak); algorithmic FLOPs = 2*M*N*K.
+#include <stdlib.h>
+
 #include "common.h"
 
 enum { MODE_GATHER = 0, MODE_PARITY = 1 };
@@ -264,6 +266,11 @@ static ConvPlan plan_conv(int mode, long Mmax, int N, int nkt_min) {
     else { pl.cfg = 1; pl.BM = 128; pl.BN = 64; }
   } else if (N == 32) { pl.cfg = 2; pl.BM = 256; pl.BN = 32; }
   else { pl.cfg = 3; pl.BM = 256; pl.BN = 16; }
+  if (const char* e = getenv("SVS_CONV_CFG")) {      // sweeps only
+    static const int bm[6] = {128, 128, 256, 256, 32, 64}, bn[6] = {128, 64, 32, 16, 128, 64};
+    const int c = atoi(e);
+    if (c >= 0 && c < 6 && N % bn[c] == 0) { pl.cfg = c; pl.BM = bm[c]; pl.BN = bn[c]; }
+  }
   pl.mtiles = (Mmax + pl.BM - 1) / pl.BM;
   pl.grid_y = (mode == MODE_PARITY) ? 4 : 1;
   const long blocks = pl.mtiles * (N / pl.BN) * pl.grid_y;
@@ -275,6 +282,7 @@ static ConvPlan plan_conv(int mode, long Mmax, int N, int nkt_min) {
     if (ks > 64) ks = 64;
     if (ks < 1) ks = 1;
   }
+  if (const char* e = getenv("SVS_CONV_KSPLIT")) { int f = atoi(e); if (f >= 1 && f <= nkt_min) ks = f; }
   pl.ksplit = ks;
   return pl;
 }

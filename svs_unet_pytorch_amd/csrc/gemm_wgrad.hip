@@ -13,7 +13,9 @@
 // reproducible, no atomics) while transposing into torch's (cs,cl,kh,kw) layout.
 //
 // Bound: MFMA; algorithmic FLOPs = 2 * Cs * 25*Cl * B*Hs*Ws.
-#include "common.h"
+#include <stdlib.h>
+
+#include "internal.h"
 
 struct WgradArgs {
   const float* s; long lds; int Hs, Ws, Cs;
@@ -149,20 +151,27 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(WgradArgs p) {
     }
 }
 
-// dw[(cs*Cl + cl)*25 + tap] = sum_z slab[z][cs][tap*Cl + cl]
+// dw[(cs*Cl + cl)*25 + tap] = sum_z slab[z][cs][tap*Cl + cl].  One block per (cs, 64-channel chunk of cl):
+// slabs are read along cl (coalesced), transposed through LDS, and written as one contiguous run of dw.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int ksplit, int Cs, int Cl,
                                                            float* __restrict__ dw) {
-  const long total = (long)Cs * Cl * 25;
-  const long zstride = total;
-  for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
-    const int tap = (int)(o % 25);
-    const long cc = o / 25;
-    const int cl = (int)(cc % Cl);
-    const long cs = cc / Cl;
-    const long src = cs * (25L * Cl) + (long)tap * Cl + cl;
-    float s = 0.f;
-    for (int z = 0; z < ksplit; ++z) s += slab[z * zstride + src];
-    dw[o] = s;
+  __shared__ float tile[25][65];
+  const int clt = Cl < 64 ? Cl : 64;
+  const int cs = blockIdx.x, cl0 = blockIdx.y * clt;
+  const long zstride = (long)Cs * Cl * 25;
+  const float* src0 = slab + (long)cs * 25 * Cl + cl0;
+  for (int e = threadIdx.x; e < 25 * clt; e += 256) {
+    const int tap = e / clt, cl = e - tap * clt;
+    const float* src = src0 + (long)tap * Cl + cl;
+    float acc = 0.f;
+    for (int z = 0; z < ksplit; ++z) acc += src[z * zstride];
+    tile[tap][cl] = acc;
+  }
+  __syncthreads();
+  float* dst = dw + ((long)cs * Cl + cl0) * 25;
+  for (int e = threadIdx.x; e < 25 * clt; e += 256) {
+    const int cl = e / 25, tap = e - cl * 25;
+    dst[e] = tile[tap][cl];
   }
 }
 
@@ -181,6 +190,7 @@ static WgradPlan plan_wgrad(int B, int Hs, int Ws, int Cs, int Cl) {
   if (ks > cap) ks = cap;
   if (ks > 512) ks = 512;
   if (ks < 1) ks = 1;
+  if (const char* e = getenv("SVS_WGRAD_KSPLIT")) { long f = atol(e); if (f >= 1 && f <= cap) ks = f; }
   long pps = (P + ks - 1) / ks;
   pps = (pps + 15) / 16 * 16;
   ks = (P + pps - 1) / pps;
@@ -189,9 +199,11 @@ static WgradPlan plan_wgrad(int B, int Hs, int Ws, int Cs, int Cl) {
   return pl;
 }
 
+#define WG_GROUPS 8      // slabs are pre-summed in WG_GROUPS parallel groups when there are many of them
+
 size_t svs_wgrad_gemm_workspace(int B, int Hs, int Ws, int Cs, int Cl) {
   WgradPlan pl = plan_wgrad(B, Hs, Ws, Cs, Cl);
-  return (size_t)pl.ksplit * Cs * 25 * Cl * sizeof(float);
+  return (size_t)(pl.ksplit + WG_GROUPS) * Cs * 25 * Cl * sizeof(float);
 }
 
 int svs_wgrad_gemm_run(const float* s, long lds, int B, int Hs, int Ws, int Cs, const float* l, long ldl, int Hl,
@@ -202,7 +214,7 @@ int svs_wgrad_gemm_run(const float* s, long lds, int B, int Hs, int Ws, int Cs, 
   SVS_REQUIRE(lds >= Cs && lds % 4 == 0 && ldl >= Cl && ldl % 4 == 0, "%s: bad ld", who);
   SVS_REQUIRE(svs_aligned16(s) && svs_aligned16(l) && svs_aligned16(ws), "%s: pointers must be 16-byte aligned", who);
   WgradPlan pl = plan_wgrad(B, Hs, Ws, Cs, Cl);
-  const size_t need = (size_t)pl.ksplit * Cs * 25 * Cl * sizeof(float);
+  const size_t need = svs_wgrad_gemm_workspace(B, Hs, Ws, Cs, Cl);
   if (!ws || ws_bytes < need) {
     svs_set_error("%s: workspace too small (%zu < %zu)", who, ws_bytes, need);
     return SVS_ERR_WORKSPACE;
@@ -218,10 +230,19 @@ int svs_wgrad_gemm_run(const float* s, long lds, int B, int Hs, int Ws, int Cs, 
     default: hipLaunchKernelGGL((wgrad_gemm_kernel<32, 128, 1, 4>), grid, dim3(256), 0, stream, a); break;
   }
   SVS_CHECK_LAUNCH("wgrad_gemm");
-  const long total = (long)Cs * Cl * 25;
-  int rg = (int)((total + 255) / 256);
-  if (rg > 4096) rg = 4096;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rg), dim3(256), 0, stream, (const float*)ws, pl.ksplit, Cs, Cl, dw);
+  const long n = (long)Cs * 25 * Cl;
+  const float* slabs = (const float*)ws;
+  int nslab = pl.ksplit;
+  if (nslab > 2 * WG_GROUPS) {     // long serial chains per output element: sum in WG_GROUPS parallel groups first
+    float* tmp = (float*)ws + (size_t)pl.ksplit * n;
+    const int per = (nslab + WG_GROUPS - 1) / WG_GROUPS;
+    const int groups = (nslab + per - 1) / per;
+    if (int rc = svs_reduce_slabs_run(slabs, nslab, per, groups, n, tmp, stream)) return rc;
+    slabs = tmp;
+    nslab = groups;
+  }
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)Cs, (unsigned)((Cl + 63) / 64)), dim3(256), 0, stream, slabs, nslab, Cs,
+                     Cl, dw);
   SVS_CHECK_LAUNCH("wgrad_reduce");
   return SVS_OK;
 }

@@ -26,3 +26,6 @@ size_t svs_wgrad_c1_workspace(int B, int Hs, int Ws, int Cs);
 int svs_channel_sum_run(const float* x, long ldx, long P, int C, float* out, void* ws, size_t ws_bytes, hipStream_t stream);
 int svs_sum_run(const float* x, long n, float* out, void* ws, size_t ws_bytes, hipStream_t stream);
 int svs_sigmoid_bwd_run(const float* mask, const float* dmask, long n, float* d_logit, hipStream_t stream);
+
+// out[g][i] = sum over the g-th chunk of `per` consecutive slabs of slab[z][i]   (i < n, g < groups)
+int svs_reduce_slabs_run(const float* slab, int nslab, int per, int groups, long n, float* out, hipStream_t stream);

@@ -7,7 +7,7 @@
 // All three give each pixel's channel vector to COUT/4 (CIN/4) adjacent lanes as float4, so the wide
 // side is read/written in contiguous 16-byte pieces; the single-channel image is read through L1.
 // Bound: HBM.  Algorithmic bytes: the NHWC tensor once + the 1-channel image once.
-#include "common.h"
+#include "internal.h"
 
 struct C1Args {
   const float* x; int B, H, W;            // (B,H,W) single channel
@@ -232,24 +232,36 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(WgC1Args p) {
   for (int i = t; i < 25 * CS; i += 256) out[i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
 }
 
-__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slab, int nslab, long n,
+// out[g][i] = sum of slabs z in group g (contiguous chunks of `per` slabs); grid (ceil(n/256), groups)
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slab, int nslab, int per, long n,
                                                            float* __restrict__ out) {
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    float s = 0.f;
-    for (int z = 0; z < nslab; ++z) s += slab[(long)z * n + i];
-    out[i] = s;
-  }
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int z0 = blockIdx.y * per;
+  int z1 = z0 + per;
+  if (z1 > nslab) z1 = nslab;
+  float s = 0.f;
+  for (int z = z0; z < z1; ++z) s += slab[(long)z * n + i];
+  out[(long)blockIdx.y * n + i] = s;
 }
 
+int svs_reduce_slabs_run(const float* slab, int nslab, int per, int groups, long n, float* out, hipStream_t stream) {
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)groups), dim3(256), 0, stream, slab, nslab, per, n, out);
+  SVS_CHECK_LAUNCH("reduce_slabs");
+  return SVS_OK;
+}
+
+#define C1_GROUPS 32
+
 static int wgrad_c1_blocks(long P) {
-  long nb = (P + 1023) / 1024;
-  if (nb > 2048) nb = 2048;
+  long nb = (P + 2047) / 2048;
+  if (nb > 1024) nb = 1024;
   if (nb < 1) nb = 1;
   return (int)nb;
 }
 
 size_t svs_wgrad_c1_workspace(int B, int Hs, int Ws, int Cs) {
-  return (size_t)wgrad_c1_blocks((long)B * Hs * Ws) * 25 * Cs * sizeof(float);
+  return (size_t)(wgrad_c1_blocks((long)B * Hs * Ws) + C1_GROUPS) * 25 * Cs * sizeof(float);
 }
 
 int svs_wgrad_c1_run(const float* s, long lds, int B, int Hs, int Ws, int Cs, const float* l, int Hl, int Wl,
@@ -260,7 +272,7 @@ int svs_wgrad_c1_run(const float* s, long lds, int B, int Hs, int Ws, int Cs, co
   SVS_REQUIRE(lds >= Cs && lds % 4 == 0 && svs_aligned16(s), "%s: bad view", who);
   const long P = (long)B * Hs * Ws;
   const int nb = wgrad_c1_blocks(P);
-  const size_t need = (size_t)nb * 25 * Cs * sizeof(float);
+  const size_t need = svs_wgrad_c1_workspace(B, Hs, Ws, Cs);
   if (!ws || ws_bytes < need) {
     svs_set_error("%s: workspace too small (%zu < %zu)", who, ws_bytes, need);
     return SVS_ERR_WORKSPACE;
@@ -270,7 +282,13 @@ int svs_wgrad_c1_run(const float* s, long lds, int B, int Hs, int Ws, int Cs, co
   else hipLaunchKernelGGL(wgrad_c1_kernel<32>, dim3(nb), dim3(256), 0, stream, a);
   SVS_CHECK_LAUNCH("wgrad_c1");
   const long n = 25L * Cs;
-  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const float*)ws, nb, n, dw);
+  float* tmp = (float*)ws + (size_t)nb * n;
+  const int groups = nb < C1_GROUPS ? nb : C1_GROUPS;
+  const int per = (nb + groups - 1) / groups;
+  const unsigned gx = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(gx, (unsigned)groups), dim3(256), 0, stream, (const float*)ws, nb, per, n, tmp);
+  SVS_CHECK_LAUNCH("reduce_slabs");
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(gx, 1), dim3(256), 0, stream, (const float*)tmp, groups, groups, n, dw);
   SVS_CHECK_LAUNCH("reduce_slabs");
   return SVS_OK;
 }
