@@ -266,6 +266,9 @@ static ConvPlan plan_conv(int mode, long Mmax, int N, int nkt_min) {
     else { pl.cfg = 1; pl.BM = 128; pl.BN = 64; }
   } else if (N == 32) { pl.cfg = 2; pl.BM = 256; pl.BN = 32; }
   else { pl.cfg = 3; pl.BM = 256; pl.BN = 16; }
+  // Parity blocks differ in length (9/6/6/4 taps): many small tiles balance better than few big ones
+  // (tools/gemm_sweep.py, B=64: 64x64 tiles beat 128-wide ones by 10-20% whenever M per parity > 1024).
+  if (mode == MODE_PARITY && N % 64 == 0 && Mmax > 1024) { pl.cfg = 5; pl.BM = 64; pl.BN = 64; }
   if (const char* e = getenv("SVS_CONV_CFG")) {      // sweeps only
     static const int bm[6] = {128, 128, 256, 256, 32, 64}, bn[6] = {128, 64, 32, 16, 128, 64};
     const int c = atoi(e);
@@ -275,8 +278,9 @@ static ConvPlan plan_conv(int mode, long Mmax, int N, int nkt_min) {
   pl.grid_y = (mode == MODE_PARITY) ? 4 : 1;
   const long blocks = pl.mtiles * (N / pl.BN) * pl.grid_y;
   int ks = 1;
-  if (blocks < 384) {
-    ks = (int)((768 + blocks - 1) / blocks);
+  const long target = (mode == MODE_PARITY) ? 1024 : 768;
+  if (blocks < ((mode == MODE_PARITY) ? 768 : 384)) {
+    ks = (int)((target + blocks - 1) / blocks);
     const int cap = nkt_min / 8 > 1 ? nkt_min / 8 : 1;   // keep >= 8 K-tiles per split
     if (ks > cap) ks = cap;
     if (ks > 64) ks = 64;

@@ -1,0 +1,89 @@
+"""End-to-end CLI parity (-m gpu): wav -> data.py to_spec -> train.py (a few steps) -> inference.py ->
+data.py to_wave on synthetic audio, with every intermediate file checked against the oracle
+(oracle/stft_oracle.py, oracle/tiling_oracle.py, oracle/unet_oracle.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import stft_oracle as so
+from oracle import tiling_oracle as to
+from oracle import unet_oracle as uo
+from svs_unet_pytorch_amd import data as svs_data
+from svs_unet_pytorch_amd import inference as svs_inference
+from svs_unet_pytorch_amd import synth
+from svs_unet_pytorch_amd import train as svs_train
+
+pytestmark = pytest.mark.gpu
+SR = 8192
+
+
+def _write_song(folder, idx, n):
+    from scipy.io import wavfile
+    os.makedirs(folder, exist_ok=True)
+    voc = synth.audio(n - 1000, 2 * idx) * 0.3
+    acc = synth.audio(n, 2 * idx + 1) * 0.5
+    mix = acc.copy()
+    mix[: voc.size] += voc
+    wavfile.write(os.path.join(folder, "mixture.wav"), SR, mix.astype(np.float32))
+    wavfile.write(os.path.join(folder, "vocals.wav"), SR, voc.astype(np.float32))       # shorter: exercises data.py:97-98
+    return mix.astype(np.float32), voc.astype(np.float32)
+
+
+def test_pipeline_end_to_end(tmp_path, report, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    src = tmp_path / "wav"
+    songs = {name: _write_song(str(src / name), i, n) for i, (name, n) in enumerate((("songA", 110000), ("songB", 99000)))}
+    spec_dir = tmp_path / "spec"
+    svs_data.main(["--src", str(src), "--tar", str(spec_dir), "--direction", "to_spec"])
+    names = sorted(os.listdir(spec_dir / "mixture"))
+    assert names == ["0000_songA_phase.npy", "0000_songA_spec.npy", "0001_songB_phase.npy", "0001_songB_spec.npy"]   # data.py:107-109
+    for i, (name, (mix, voc)) in enumerate(songs.items()):
+        for track, y in (("mixture", mix), ("vocal", voc)):
+            spec = np.load(spec_dir / track / f"{i:04d}_{name}_spec.npy")
+            phase = np.load(spec_dir / track / f"{i:04d}_{name}_phase.npy")
+            want_s, want_p = so.to_spec(mix, y)
+            assert spec.dtype == np.float32 and phase.dtype == np.complex64 and spec.shape == want_s.shape == (513, 1 + mix.size // 768)
+            assert report(f"cli to_spec {name}/{track} magnitude", np.abs(spec - want_s).max(), 2e-6)
+            strong = want_s > 1e-3                      # the phase of a near-zero bin is noise in any fp32 FFT
+            assert report(f"cli to_spec {name}/{track} phase", np.abs(phase - want_p)[strong].max(), 2e-3)
+        assert abs(np.load(spec_dir / "mixture" / f"{i:04d}_{name}_spec.npy").max() - 1.0) <= 1e-6
+
+    # a short training run through the CLI: files and keys of train.py:169-171,369-382
+    svs_train.main(["--train_folder", str(spec_dir), "--valid_folder", str(spec_dir), "--label", "t", "--epoch", "2", "--batch_size", "8",
+                    "--val_interval", "1", "--load_path", "none.pth"])
+    ck = torch.load(tmp_path / "CKPT" / "svs_t.pth", map_location="cpu")
+    assert ck["epoch"] == 2 and len(ck["model_state_dict"]) == 79 and "optim" in ck and "scheduler" in ck
+    assert os.path.exists(tmp_path / "CKPT" / "svs_best_t.pth")
+    lines = open(tmp_path / "LOG" / "log_t.txt").read().split()
+    assert len([x for x in lines if x == "Val"]) == 2 and all(np.isfinite(float(x)) for x in lines if x != "Val")
+
+    # inference through the CLI with the trained checkpoint, checked against the oracle on the same weights
+    pred_dir = tmp_path / "pred"
+    svs_inference.main(["--model_path", str(tmp_path / "CKPT" / "svs_t.pth"), "--mixture_folder", str(spec_dir / "mixture"),
+                        "--tar", str(pred_dir), "--vocal_solo", "1"])
+    st = {k: v.clone() for k, v in ck["model_state_dict"].items()}
+    for i, name in enumerate(songs):
+        fname = f"{i:04d}_{name}_spec.npy"
+        got = np.load(pred_dir / fname)
+        mixspec = np.load(spec_dir / "mixture" / fname)
+        with torch.no_grad():
+            want = to.separate(mixspec, lambda t: uo.forward(st, torch.from_numpy(t)).numpy())
+        assert got.shape == mixspec.shape and np.all(got[0] == 0)
+        assert report(f"cli inference {name}", np.abs(got - want).max(), 1e-4)
+
+    # back to audio
+    wav_dir = tmp_path / "out_wav"
+    svs_data.main(["--src", str(pred_dir), "--phase", str(spec_dir / "mixture"), "--tar", str(wav_dir), "--direction", "to_wave"])
+    from scipy.io import wavfile
+    for i, name in enumerate(songs):
+        rate, y = wavfile.read(wav_dir / f"{i:04d}_{name}.wav")
+        mag = np.load(pred_dir / f"{i:04d}_{name}_spec.npy")
+        ph = np.load(spec_dir / "mixture" / f"{i:04d}_{name}_phase.npy")
+        want = so.to_wave(mag, ph)
+        assert rate == SR and y.shape == want.shape
+        assert abs(np.abs(y).max() - 0.9) <= 1e-5                                     # data.py:162-164
+        assert report(f"cli to_wave {name} (interior)", np.abs(y - want)[1024:-1024].max(), 5e-5)
+    with pytest.raises(Exception):
+        svs_data.main(["--src", str(pred_dir), "--tar", str(wav_dir), "--direction", "to_wave"])    # data.py:118

