@@ -113,10 +113,18 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs p) {
   }
 
   f32x4 ra[RA], rb[RB];
+  // (tap row, tap column, channel chunk) of the next tile to load; tiles are loaded in order from kt_begin
+  int l_th, l_tw, l_cc;
+  {
+    const int tap = kt_begin / cpt;
+    l_cc = kt_begin - tap * cpt;
+    l_th = tap / ntw;
+    l_tw = tap - l_th * ntw;
+  }
   auto load_tile = [&](int kt) {
-    const int tap = kt / cpt;
-    const int c0 = (kt - tap * cpt) << 4;
-    const int th = tap / ntw, tw = tap - th * ntw;
+    const int c0 = l_cc << 4;
+    const int th = l_th, tw = l_tw;
+    if (++l_cc == cpt) { l_cc = 0; if (++l_tw == ntw) { l_tw = 0; ++l_th; } }
 #pragma unroll
     for (int r = 0; r < RA; ++r) {
       const int ih = (MODE == MODE_GATHER) ? a_h[r] + th : a_h[r] - th;

@@ -23,6 +23,7 @@ struct WgradArgs {
   int B;
   float* slab;           // [ksplit][Cs][25*Cl]
   long pix_per_split;    // multiple of 16
+  int ws_shift, hs_shift; // log2 of Ws / Hs when they are powers of two, else -1
 };
 
 template <int BM, int BN, int WM, int WN>
@@ -69,8 +70,34 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(WgradArgs p) {
     bkh[r] = tap / 5; bkw[r] = tap - bkh[r] * 5;
   }
 
+  // (b, i, j) of each B row's pixel, advanced by 16 pixels per K-tile with 32-bit arithmetic
+  // (a 64-bit divide per row per tile used to cost more VALU time than the tile's MFMAs)
+  int bj[RB], bi[RB]; long bimg[RB];
+#pragma unroll
+  for (int r = 0; r < RB; ++r) {
+    const unsigned pix = (unsigned)(p_begin + bk[r]);
+    const unsigned row = pix / (unsigned)p.Ws;
+    bj[r] = (int)(pix - row * (unsigned)p.Ws);
+    const unsigned img = row / (unsigned)p.Hs;
+    bi[r] = (int)(row - img * (unsigned)p.Hs);
+    bimg[r] = (long)img * p.Hl * p.Wl;
+  }
+  const long img_stride = (long)p.Hl * p.Wl;
+  auto advance = [&]() {
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      unsigned j = (unsigned)bj[r] + 16u, i = (unsigned)bi[r];
+      if (p.ws_shift >= 0) { i += j >> p.ws_shift; j &= (unsigned)p.Ws - 1u; }
+      else { const unsigned q = j / (unsigned)p.Ws; j -= q * (unsigned)p.Ws; i += q; }
+      unsigned nb;
+      if (p.hs_shift >= 0) { nb = i >> p.hs_shift; i &= (unsigned)p.Hs - 1u; }
+      else { nb = i / (unsigned)p.Hs; i -= nb * (unsigned)p.Hs; }
+      bj[r] = (int)j; bi[r] = (int)i; bimg[r] += (long)nb * img_stride;
+    }
+  };
+
   f32x4 ra[RA], rb[RB];
-  auto load_tile = [&](long pk) {
+  auto load_tile = [&](long pk) {      // must be called with pk advancing by 16 from p_begin
 #pragma unroll
     for (int r = 0; r < RA; ++r) {
       const long pix = pk + ak[r];
@@ -80,19 +107,15 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(WgradArgs p) {
     }
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
-      const long pix = pk + bk[r];
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (bok[r] && pix < p_end) {
-        const int j = (int)(pix % p.Ws);
-        const long tmp = pix / p.Ws;
-        const int i = (int)(tmp % p.Hs);
-        const long b = tmp / p.Hs;
-        const int ih = 2 * i - 2 + bkh[r], iw = 2 * j - 2 + bkw[r];
+      if (bok[r] && pk + bk[r] < p_end) {
+        const int ih = 2 * bi[r] - 2 + bkh[r], iw = 2 * bj[r] - 2 + bkw[r];
         if ((unsigned)ih < (unsigned)p.Hl && (unsigned)iw < (unsigned)p.Wl)
-          v = *(const f32x4*)(p.l + ((b * p.Hl + ih) * p.Wl + iw) * p.ldl + bcl[r]);
+          v = *(const f32x4*)(p.l + (bimg[r] + (long)ih * p.Wl + iw) * p.ldl + bcl[r]);
       }
       rb[r] = v;
     }
+    advance();
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
@@ -223,6 +246,9 @@ int svs_wgrad_gemm_run(const float* s, long lds, int B, int Hs, int Ws, int Cs, 
   a.s = s; a.lds = lds; a.Hs = Hs; a.Ws = Ws; a.Cs = Cs;
   a.l = l; a.ldl = ldl; a.Hl = Hl; a.Wl = Wl; a.Cl = Cl;
   a.B = B; a.slab = (float*)ws; a.pix_per_split = pl.pps;
+  auto log2_or_neg = [](int v) { int s = 0; while ((1 << s) < v) ++s; return (1 << s) == v ? s : -1; };
+  a.ws_shift = log2_or_neg(Ws); a.hs_shift = log2_or_neg(Hs);
+  SVS_REQUIRE((long)B * Hs * Ws < (1L << 31), "%s: pixel count exceeds 2^31", who);
   dim3 grid((unsigned)(Cs / pl.BM), (unsigned)((25 * Cl + pl.BN - 1) / pl.BN), (unsigned)pl.ksplit);
   switch (pl.cfg) {
     case 0: hipLaunchKernelGGL((wgrad_gemm_kernel<128, 128, 2, 2>), grid, dim3(256), 0, stream, a); break;

@@ -16,52 +16,66 @@ struct C1Args {
   float* y; long ldy; int Ho, Wo; int accumulate;
 };
 
+// One thread = one output pixel, all COUT channels: the 25 input samples are loaded once per pixel (the
+// earlier 4-channels-per-thread mapping re-issued them COUT/4 times and was bound by load issue), the
+// weights are wave-uniform and come through the scalar cache, and the COUT results go through an LDS
+// transpose so that the global stores are contiguous 16-byte pieces of each pixel's channel vector.
 template <int COUT>
 __global__ __launch_bounds__(256) void conv_c1_kernel(C1Args p) {
   constexpr int G = COUT / 4;
-  __shared__ __attribute__((aligned(16))) float wl[25 * COUT];   // [tap][n]
-  for (int i = threadIdx.x; i < 25 * COUT; i += 256) {
-    const int n = i / 25, tap = i - n * 25;
-    wl[tap * COUT + n] = p.w[i];
-  }
-  __syncthreads();
-  const long total = (long)p.B * p.Ho * p.Wo * G;
-  for (long gid = (long)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (long)gridDim.x * 256) {
-    const int cg = (int)(gid % G);
-    const long pix = gid / G;
+  constexpr int LD = COUT + 4;
+  __shared__ __attribute__((aligned(16))) float tile[256 * LD];
+  const float* __restrict__ w = p.w;
+  const long P = (long)p.B * p.Ho * p.Wo;
+  const long pix0 = (long)blockIdx.x * 256;
+  const long pix = pix0 + threadIdx.x;
+  if (pix < P) {
     const int ow = (int)(pix % p.Wo);
     const long tmp = pix / p.Wo;
     const int oh = (int)(tmp % p.Ho);
     const long b = tmp / p.Ho;
     const float* img = p.x + b * p.H * p.W;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float xin[25];
 #pragma unroll
     for (int kh = 0; kh < 5; ++kh) {
       const int ih = 2 * oh - 2 + kh;
-      if ((unsigned)ih >= (unsigned)p.H) continue;
 #pragma unroll
       for (int kw = 0; kw < 5; ++kw) {
         const int iw = 2 * ow - 2 + kw;
-        if ((unsigned)iw >= (unsigned)p.W) continue;
-        const float v = img[(long)ih * p.W + iw];
-        const f32x4 w4 = *(const f32x4*)(&wl[(kh * 5 + kw) * COUT + cg * 4]);
-        acc += w4 * v;
+        float v = 0.f;
+        if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) v = img[(long)ih * p.W + iw];
+        xin[kh * 5 + kw] = v;
       }
     }
-    const int n = cg * 4;
-    float* dst = p.y + pix * p.ldy + n;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float v = acc[k];
-      if (p.bias) v += p.bias[n + k];
-      if (p.scale) {
-        v = v * p.scale[n + k] + p.shift[n + k];
-        v = v > 0.f ? v : v * p.slope;
+    for (int g = 0; g < G; ++g) {
+      f32x4 acc;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int n = g * 4 + k;
+        float a = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 25; ++tap) a += xin[tap] * w[n * 25 + tap];
+        if (p.scale) {
+          a = a * p.scale[n] + p.shift[n];
+          a = a > 0.f ? a : a * p.slope;
+        }
+        acc[k] = a;
       }
-      if (p.accumulate) v += dst[k];
-      acc[k] = v;
+      *(f32x4*)(&tile[threadIdx.x * LD + g * 4]) = acc;
     }
-    *(f32x4*)dst = acc;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < G; ++r) {
+    const int id = threadIdx.x + 256 * r;
+    const int pp = id / G, sub = id - pp * G;
+    if (pix0 + pp < P) {
+      f32x4 v = *(const f32x4*)(&tile[pp * LD + sub * 4]);
+      float* dst = p.y + (pix0 + pp) * p.ldy + sub * 4;
+      if (p.accumulate) v += *(const f32x4*)dst;
+      *(f32x4*)dst = v;
+    }
   }
 }
 
@@ -72,9 +86,8 @@ int svs_conv_c1_run(const float* x, int B, int H, int W, const float* w, const f
   SVS_REQUIRE(N == 16 || N == 32, "%s: single-channel conv supports N=16/32, got %d", who, N);
   SVS_REQUIRE(ldy >= N && ldy % 4 == 0 && svs_aligned16(y), "%s: bad output view", who);
   C1Args a{x, B, H, W, w, bias, scale, shift, slope, y, ldy, svs_conv_out(H), svs_conv_out(W), accumulate};
-  const long total = (long)B * a.Ho * a.Wo * (N / 4);
-  int grid = (int)((total + 255) / 256);
-  if (grid > 8192) grid = 8192;
+  const long total = (long)B * a.Ho * a.Wo;
+  const int grid = (int)((total + 255) / 256);
   if (N == 16) hipLaunchKernelGGL(conv_c1_kernel<16>, dim3(grid), dim3(256), 0, stream, a);
   else hipLaunchKernelGGL(conv_c1_kernel<32>, dim3(grid), dim3(256), 0, stream, a);
   SVS_CHECK_LAUNCH("conv_c1");
