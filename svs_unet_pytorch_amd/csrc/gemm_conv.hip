@@ -37,6 +37,7 @@ struct ConvGemmArgs {
   int accumulate;
   int ksplit;                     // gridDim.z
   float* slab;                    // [ksplit][B*Ho*Wo][N] partial sums when ksplit > 1
+  int tap_inner;                  // K-tile order: 1 = channel chunk outer / tap inner, 0 = tap outer / chunk inner
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 3); }
@@ -116,15 +117,18 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs p) {
   // (tap row, tap column, channel chunk) of the next tile to load; tiles are loaded in order from kt_begin
   int l_th, l_tw, l_cc;
   {
-    const int tap = kt_begin / cpt;
-    l_cc = kt_begin - tap * cpt;
+    int tap;
+    if (p.tap_inner) { l_cc = kt_begin / ntaps; tap = kt_begin - l_cc * ntaps; }
+    else { tap = kt_begin / cpt; l_cc = kt_begin - tap * cpt; }
     l_th = tap / ntw;
     l_tw = tap - l_th * ntw;
   }
-  auto load_tile = [&](int kt) {
+  auto load_tile = [&](int) {
     const int c0 = l_cc << 4;
     const int th = l_th, tw = l_tw;
-    if (++l_cc == cpt) { l_cc = 0; if (++l_tw == ntw) { l_tw = 0; ++l_th; } }
+    const long koff = (long)(th * ntw + tw) * p.C + c0;      // column of this tile in the packed weight rows
+    if (p.tap_inner) { if (++l_tw == ntw) { l_tw = 0; if (++l_th == nth) { l_th = 0; ++l_cc; } } }
+    else { if (++l_cc == cpt) { l_cc = 0; if (++l_tw == ntw) { l_tw = 0; ++l_th; } } }
 #pragma unroll
     for (int r = 0; r < RA; ++r) {
       const int ih = (MODE == MODE_GATHER) ? a_h[r] + th : a_h[r] - th;
@@ -137,7 +141,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs p) {
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (b_ok[r]) v = *(const f32x4*)(b_row[r] + (long)kt * 16);
+      if (b_ok[r]) v = *(const f32x4*)(b_row[r] + koff);
       rb[r] = v;
     }
   };
@@ -226,6 +230,145 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs p) {
           if (p.accumulate) v += *dst;
           *dst = v;
         }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS-free variant for the layers with few output channels (N = 16 / 32: conv2, deconv4/5 and the
+// backward-data of conv2/conv3).  With N that small every im2col element feeds only N MACs, so moving it
+// global -> VGPR -> LDS -> VGPR (three wide data-movement instructions per 4 MFMAs, none of which overlaps the
+// fp32 MFMA on a SIMD: tools/mfma_valu_probe.hip) costs more issue time than the MFMAs themselves.  Here each
+// lane loads its MFMA fragment straight from global memory: lane (row r, quarter q) of row-tile i reads the 16
+// bytes x[pixel(i, r)][c0 + 4q .. 4q+3], i.e. the four k it supplies to four consecutive MFMAs, with ONE
+// buffer load (hardware range check = zero padding, 25-bit validity mask per row decided once, tap / chunk
+// offset in an SGPR).  No LDS, no barriers, waves are independent; fragments are double-buffered in registers.
+// ------------------------------------------------------------------------------------------------
+template <int MODE, int TM, int TN>
+__global__ __launch_bounds__(256) void conv_direct_kernel(ConvGemmArgs p) {
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int lrow = lane & 15, q = lane >> 4;
+  int ph = 0, pw = 0, nth = 5, ntw = 5, Ha, Wa;
+  const float* wp = p.wp;
+  if (MODE == MODE_PARITY) {
+    const int par = blockIdx.y;
+    ph = par >> 1; pw = par & 1;
+    nth = 3 - ph; ntw = 3 - pw;
+    Ha = (p.Ho - ph + 1) >> 1; Wa = (p.Wo - pw + 1) >> 1;
+    const int poff = (par == 0) ? 0 : (par == 1) ? 9 : (par == 2) ? 15 : 21;
+    wp += (long)poff * p.N * p.C;
+  } else {
+    Ha = p.Ho; Wa = p.Wo;
+  }
+  const int ntaps = nth * ntw;
+  const long M = (long)p.B * Ha * Wa;
+  const long m0 = ((long)blockIdx.x * 4 + wave) * (TM * 16);
+  if (m0 >= M) return;
+  const int cpt = p.C >> 4;
+  const int nkt = ntaps * cpt;
+  const long Kw = (long)ntaps * p.C;
+  constexpr unsigned OOB = 0x80000000u;
+
+  unsigned a_voff[TM], a_mask[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const long m = m0 + i * 16 + lrow;
+    const bool ok = m < M;
+    const long mm = ok ? m : 0;
+    const int wq = (int)(mm % Wa);
+    const long tmp = mm / Wa;
+    const int hq = (int)(tmp % Ha);
+    const long b = tmp / Ha;
+    const int h0 = (MODE == MODE_GATHER) ? 2 * hq : hq;
+    const int w0 = (MODE == MODE_GATHER) ? 2 * wq : wq;
+    a_voff[i] = ok ? (unsigned)((((b * p.H + h0) * p.W + w0) * p.ldx + q * 4) * 4) : OOB;
+    unsigned mask = 0;
+    for (int th = 0; th < nth; ++th)
+      for (int tw = 0; tw < ntw; ++tw) {
+        const int ih = (MODE == MODE_GATHER) ? h0 - 2 + th : h0 + 1 - th;
+        const int iw = (MODE == MODE_GATHER) ? w0 - 2 + tw : w0 + 1 - tw;
+        if (ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) mask |= 1u << (th * ntw + tw);
+      }
+    a_mask[i] = mask;
+  }
+  unsigned b_voff[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) b_voff[j] = (unsigned)(((long)(j * 16 + lrow) * Kw + q * 4) * 4);
+  // base shifted so that every per-tile scalar offset is >= 0 (see conv_gemm_kernel for the tap geometry)
+  const long shift = (MODE == MODE_GATHER) ? (2L * p.W + 2) * p.ldx : (1L * p.W + 1) * p.ldx;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x - shift), 0, OOB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wp, 0, OOB, 0x00020000);
+
+  int l_th = 0, l_tw = 0, l_cc = 0;        // chunk outer, tap inner
+  auto load_frags = [&](f32x4 (&fa)[TM], f32x4 (&fb)[TN]) {
+    const int th = l_th, tw = l_tw, tap = th * ntw + tw;
+    const int pix = (MODE == MODE_GATHER) ? th * p.W + tw : (2 - th) * p.W + (2 - tw);
+    const int soff_a = (int)((pix * p.ldx + (l_cc << 4)) * 4);
+    const int soff_b = (int)(((long)tap * p.C + (l_cc << 4)) * 4);
+    if (++l_tw == ntw) { l_tw = 0; if (++l_th == nth) { l_th = 0; ++l_cc; } }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const unsigned vo = ((a_mask[i] >> tap) & 1u) ? a_voff[i] : OOB;
+      fa[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)vo, soff_a, 0));
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+      fb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (int)b_voff[j], soff_b, 0));
+  };
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  auto mma = [&](const f32x4 (&fa)[TM], const f32x4 (&fb)[TN]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][k], fb[j][k], acc[i][j], 0, 0, 0);
+  };
+  f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+  load_frags(fa0, fb0);
+  for (int kt = 0; kt < nkt; kt += 2) {
+    if (kt + 1 < nkt) load_frags(fa1, fb1);
+    mma(fa0, fb0);
+    if (kt + 1 < nkt) {
+      if (kt + 2 < nkt) load_frags(fa0, fb0);
+      mma(fa1, fb1);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long m = m0 + i * 16 + q * 4 + r;
+      if (m >= M) continue;
+      long opix;
+      if (MODE == MODE_GATHER) {
+        opix = m;
+      } else {
+        const int wq = (int)(m % Wa);
+        const long tmp = m / Wa;
+        const int hq = (int)(tmp % Ha);
+        const long b = tmp / Ha;
+        opix = (b * p.Ho + 2 * hq + ph) * p.Wo + 2 * wq + pw;
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = j * 16 + lrow;
+        float v = acc[i][j][r];
+        if (p.bias) v += p.bias[n];
+        if (p.scale) {
+          v = v * p.scale[n] + p.shift[n];
+          v = v > 0.f ? v : v * p.slope;
+        }
+        float* dst = p.y + opix * p.ldy + n;
+        if (p.accumulate) v += *dst;
+        *dst = v;
       }
     }
   }
@@ -351,6 +494,11 @@ int svs_conv_gemm_run(int mode, const float* x, long ldx, int B, int H, int W, i
   a.bias = bias; a.scale = scale; a.shift = shift; a.slope = slope;
   a.y = y; a.ldy = ldy; a.Ho = Ho; a.Wo = Wo; a.N = N; a.accumulate = accumulate;
   a.ksplit = pl.ksplit; a.slab = nullptr;
+  // With few output channels the im2col operand dominates the traffic; consuming all taps of a 16-channel
+  // chunk before the next chunk keeps a block's re-read window in cache (same-device A/B: 5% faster for the
+  // N<=32 layers, 1-2% slower for the deep ones, hence the switch).
+  a.tap_inner = N <= 32;
+  if (const char* e = getenv("SVS_CONV_KORDER")) a.tap_inner = atoi(e) != 0;     // sweeps only
   const long P = (long)B * Ho * Wo;
   if (pl.ksplit > 1) {
     const size_t need = (size_t)pl.ksplit * P * N * sizeof(float);
@@ -359,6 +507,30 @@ int svs_conv_gemm_run(int mode, const float* x, long ldx, int B, int H, int W, i
       return SVS_ERR_WORKSPACE;
     }
     a.slab = (float*)ws;
+  }
+  // LDS-free kernel for the 16-channel outputs (same-device A/B: 1.2-1.3x there; N = 32 is mixed, so it stays on
+  // the LDS kernel except in parity mode with a deep reduction)
+  int direct = 0;
+  if (Mmax >= 16384 && ((long)B * H * W * ldx + 4L * (W + 2) * ldx) * 4 < (1L << 31)) {
+    if (N == 16) direct = 1;                                    // 64 rows per wave (128 measured slower)
+    else if (N == 32 && mode == MODE_PARITY && C >= 128) direct = 1;
+  }
+  if (const char* e = getenv("SVS_CONV_DIRECT")) { const int f = atoi(e); if (f == 0 || (N <= 32 && Mmax >= 16384)) direct = f; }  // sweeps
+  if (direct && (N == 16 || N == 32)) {
+    a.ksplit = 1; a.slab = nullptr;
+    const int rows = (direct == 2 ? 8 : 4) * 64;      // 4 independent waves per block, TM*16 output rows each
+    dim3 grid((unsigned)((Mmax + rows - 1) / rows), (unsigned)pl.grid_y, 1);
+#define SVS_LAUNCH_DIRECT(MODE_, TM_, TN_) hipLaunchKernelGGL((conv_direct_kernel<MODE_, TM_, TN_>), grid, dim3(256), 0, stream, a)
+    if (mode == MODE_GATHER) {
+      if (N == 16) { if (direct == 2) SVS_LAUNCH_DIRECT(MODE_GATHER, 8, 1); else SVS_LAUNCH_DIRECT(MODE_GATHER, 4, 1); }
+      else { if (direct == 2) SVS_LAUNCH_DIRECT(MODE_GATHER, 8, 2); else SVS_LAUNCH_DIRECT(MODE_GATHER, 4, 2); }
+    } else {
+      if (N == 16) { if (direct == 2) SVS_LAUNCH_DIRECT(MODE_PARITY, 8, 1); else SVS_LAUNCH_DIRECT(MODE_PARITY, 4, 1); }
+      else { if (direct == 2) SVS_LAUNCH_DIRECT(MODE_PARITY, 8, 2); else SVS_LAUNCH_DIRECT(MODE_PARITY, 4, 2); }
+    }
+#undef SVS_LAUNCH_DIRECT
+    SVS_CHECK_LAUNCH("conv_direct");
+    return SVS_OK;
   }
   rc = (mode == MODE_GATHER) ? launch_conv_gemm<MODE_GATHER>(a, pl, stream) : launch_conv_gemm<MODE_PARITY>(a, pl, stream);
   if (rc) return rc;

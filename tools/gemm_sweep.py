@@ -18,7 +18,8 @@ from svs_unet_pytorch_amd import _lib  # noqa: E402
 
 CH = (1, 16, 32, 64, 128, 256, 512)
 DEC = ((512, 256), (512, 128), (256, 64), (128, 32), (64, 16))
-CFG = {0: (128, 128), 1: (128, 64), 2: (256, 32), 3: (256, 16), 4: (32, 128), 5: (64, 64)}
+CFG = {0: (128, 128), 1: (128, 64), 2: (256, 32), 3: (256, 16), 4: (32, 128), 5: (64, 64), 6: (256, 128), 7: (512, 64), 8: (512, 32),
+       9: (512, 16)}
 
 
 def sizes(H=512, W=128):
@@ -44,6 +45,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--only", default="", help="comma-separated substrings of call names to run")
+    ap.add_argument("--cfgs", default="", help="comma-separated config ids to try (default all)")
+    ap.add_argument("--no-wgrad", action="store_true")
+    ap.add_argument("--ab", action="store_true", help="A/B an environment switch per call (see --ab-env)")
+    ap.add_argument("--ab-env", default="SVS_CONV_KORDER", help="switch toggled by --ab")
+    ap.add_argument("--ab-vals", default="0,1", help="comma-separated values of the switch")
     args = ap.parse_args()
     B = args.batch
     L = _lib.lib()
@@ -64,7 +71,11 @@ def main():
         calls.append((f"deconv{j + 1}.fwd", "parity", (*hw[6 - j], c), (*hw[5 - j], n)))
         calls.append((f"deconv{j + 1}.bwd_data", "gather", (*hw[5 - j], n), (*hw[6 - j], c)))
     ws = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+    only = [t for t in args.only.split(",") if t]
+    cfgs = [int(t) for t in args.cfgs.split(",") if t]
     for name, mode, (h, w, C), (ho, wo, N) in calls:
+        if only and not any(t in name for t in only):
+            continue
         x = torch.rand((B, h, w, C), device=dev) - 0.5
         wp = (torch.rand(N * C * 25, device=dev) - 0.5) * 0.05
         y = torch.empty((B, ho, wo, N), device=dev)
@@ -82,7 +93,7 @@ def main():
         emit(f"{name:18s} {mode:6s} in {h}x{w}x{C} out {ho}x{wo}x{N} {gflop:7.2f} GFLOP  default {base * 1e3:8.1f} us {gflop / base:6.1f} TF")
         best = (base, "default")
         for cfg, (bm, bn) in CFG.items():
-            if N % bn:
+            if N % bn or (cfgs and cfg not in cfgs):
                 continue
             for ks in ((1, 2, 4, 8) if not args.quick else (1, 4)):
                 os.environ["SVS_CONV_CFG"] = str(cfg)
@@ -93,11 +104,25 @@ def main():
                 emit(f"    cfg{cfg} {bm:3d}x{bn:3d} ks{ks:<3d} {t * 1e3:8.1f} us {gflop / t:6.1f} TF")
                 if t < best[0]:
                     best = (t, f"cfg{cfg} ks{ks}")
+        os.environ.pop("SVS_CONV_CFG", None)
+        os.environ.pop("SVS_CONV_KSPLIT", None)
+        if args.ab:
+            res = []
+            for rnd in range(3):               # interleaved A/B in one process (guide rule 24)
+                for ko in args.ab_vals.split(","):
+                    os.environ[args.ab_env] = ko
+                    run()
+                    res.append((ko, timeit(run)))
+            os.environ.pop(args.ab_env, None)
+            emit(f"    A/B {args.ab_env}: " + "  ".join(f"={v} {min(t for k, t in res if k == v) * 1e3:7.1f} us" for v in args.ab_vals.split(",")))
         emit(f"  -> best {best[1]} {best[0] * 1e3:.1f} us {gflop / best[0]:.1f} TF")
     os.environ.pop("SVS_CONV_CFG", None)
     os.environ.pop("SVS_CONV_KSPLIT", None)
 
     wg = []
+    if args.no_wgrad:
+        out.close()
+        return
     for k in range(2, 7):
         wg.append((f"conv{k}.bwd_weight", hw[k], CH[k], hw[k - 1], CH[k - 1]))
     for j, (c, n) in enumerate(DEC):
