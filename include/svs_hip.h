@@ -190,6 +190,15 @@ int svs_unet_train_forward(const float* params, float* bn_buffers, int64_t* num_
 int svs_unet_train_backward(const float* params, float* grads, const float* mix, const float* mask,
                             const float* d_mask, const float* drop, int B, int H, int W,
                             void* ws, size_t ws_bytes, hipStream_t stream);
+/* Split form for overlapping the data-parallel gradient exchange with the backward pass: forward + loss, then
+ * backward part 0 (decoder half: gradients of parameter tensors 24..45, i.e. grads[svs_unet_param_offset(24)..))
+ * and part 1 (encoder half: tensors 0..23).  The caller starts the all-reduce of the decoder half on a second
+ * stream as soon as part 0 is enqueued.  Same results as svs_unet_train_fwd_bwd. */
+int svs_unet_train_fwd_loss(const float* params, float* bn_buffers, int64_t* num_batches_tracked, const float* mix,
+                            const float* voc, const float* drop, int B, int H, int W, float loss_scale,
+                            float* mask /*nullable*/, float* loss, void* ws, size_t ws_bytes, hipStream_t stream);
+int svs_unet_train_bwd_part(const float* params, float* grads, const float* mix, const float* drop, int B, int H, int W,
+                            int part, void* ws, size_t ws_bytes, hipStream_t stream);
 int64_t svs_unet_ws_offset(const char* name, int B, int H, int W, int training);  /* bytes, <0 unknown */
 
 /* ---------------------------------------------------------------------------------------------

@@ -10,7 +10,8 @@ import os
 import re
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsvs_hip.so")
+# SVS_LIB_PATH: load another build of the same library (same-device A/B runs of tools/ and bench.py)
+LIB_PATH = os.environ.get("SVS_LIB_PATH") or os.path.join(HERE, "libsvs_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(HERE), "include", "svs_hip.h")
 
 _lib = None
@@ -63,6 +64,8 @@ _SIGS = {
     "svs_unet_train_fwd_bwd": (I, [P, P, P, P, P, P, P, I, I, I, F, P, P, P, Z, P]),
     "svs_unet_train_forward": (I, [P, P, P, P, P, I, I, I, P, P, Z, P]),
     "svs_unet_train_backward": (I, [P, P, P, P, P, P, I, I, I, P, Z, P]),
+    "svs_unet_train_fwd_loss": (I, [P, P, P, P, P, P, I, I, I, F, P, P, P, Z, P]),
+    "svs_unet_train_bwd_part": (I, [P, P, P, P, I, I, I, I, P, Z, P]),
     "svs_unet_ws_offset": (L, [C.c_char_p, I, I, I, I]),
     "svs_stft_frames": (I, [L, I]),
     "svs_stft_fwd": (I, [P, L, I, I, P, P, P]),

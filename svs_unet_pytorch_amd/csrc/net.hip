@@ -416,11 +416,15 @@ static int train_forward_impl(const ParamView& v, float* bn_buffers, int64_t* nb
   return svs_out_block_fwd(t.cat[1], 32, B, g.h[1], g.w[1], 32, v.w[11], v.b[11], mask, g.h[0], g.w[0], 1, stream);
 }
 
+// parts: bit 0 = decoder half (deconv6..deconv1: gradients of parameter tensors 24..45, produced FIRST),
+//        bit 1 = encoder half (conv6..conv1: tensors 0..23).  A data-parallel caller runs them as two calls and
+//        all-reduces the decoder half of the flat gradient buffer while the encoder half is still being computed.
 static int train_backward_impl(const ParamView& v, float* grads, const float* mix, const float* drop, const Geo& g,
-                               const TrainWs& t, hipStream_t stream) {
+                               const TrainWs& t, hipStream_t stream, int parts = 3) {
   const int B = g.B;
   int rc;
   auto G = [&](int idx) { return grads + svs_unet_param_offset(idx); };
+  if (parts & 1) {
   // deconv6 (model.py:109,198): dw, db, dx -> dcat[1]
   if ((rc = svs_dec_block_bwd_weight(t.cat[1], 32, B, g.h[1], g.w[1], 32, t.d_logit, 1, g.h[0], g.w[0], 1, G(44), G(45), t.scratch, t.scratch_bytes, stream))) return rc;
   if ((rc = svs_dec_block_bwd_data(t.d_logit, 1, B, g.h[0], g.w[0], 1, v.w[11], t.dcat[1], 32, g.h[1], g.w[1], 32, 0, t.scratch, t.scratch_bytes, stream))) return rc;
@@ -440,6 +444,8 @@ static int train_backward_impl(const ParamView& v, float* grads, const float* mi
     if ((rc = svs_dec_block_bwd_data(t.d_raw, N, B, g.h[lout], g.w[lout], N, t.wbwd[l], dx, C, g.h[lin], g.w[lin], C, 0,
                                      t.scratch, t.scratch_bytes, stream))) return rc;
   }
+  }
+  if (!(parts & 2)) return SVS_OK;
   // encoders 6..1
   for (int k = 6; k >= 1; --k) {
     const int l = k - 1, N = CH[k], C = CH[k - 1];
@@ -508,4 +514,29 @@ extern "C" int svs_unet_train_fwd_bwd(const float* params, float* grads, float* 
   if ((rc = train_forward_impl(v, bn_buffers, num_batches_tracked, mix, drop, g, t, m, stream))) return rc;
   if ((rc = svs_l1_mask_loss_fwd_bwd(m, mix, voc, g.P[0], loss_scale, t.d_logit, loss, t.bnws, t.bnws_bytes, stream))) return rc;
   return train_backward_impl(v, grads, mix, drop, g, t, stream);
+}
+
+// Split form of svs_unet_train_fwd_bwd for gradient-exchange overlap: forward + loss, then the backward in
+// two parts (see train_backward_impl).
+extern "C" int svs_unet_train_fwd_loss(const float* params, float* bn_buffers, int64_t* num_batches_tracked, const float* mix,
+                                       const float* voc, const float* drop, int B, int H, int W, float loss_scale, float* mask,
+                                       float* loss, void* ws, size_t ws_bytes, hipStream_t stream) {
+  Geo g; TrainWs t;
+  int rc = make_geo(B, H, W, g);
+  if (rc) return rc;
+  SVS_REQUIRE(params && mix && voc && loss && svs_aligned16(params) && svs_aligned16(mix), "svs_unet_train_fwd_loss: bad pointers");
+  if ((rc = check_train_ws("svs_unet_train_fwd_loss", g, ws, ws_bytes, t))) return rc;
+  float* m = mask ? mask : t.mask;
+  if ((rc = train_forward_impl(view_params(params), bn_buffers, num_batches_tracked, mix, drop, g, t, m, stream))) return rc;
+  return svs_l1_mask_loss_fwd_bwd(m, mix, voc, g.P[0], loss_scale, t.d_logit, loss, t.bnws, t.bnws_bytes, stream);
+}
+
+extern "C" int svs_unet_train_bwd_part(const float* params, float* grads, const float* mix, const float* drop, int B, int H, int W,
+                                       int part, void* ws, size_t ws_bytes, hipStream_t stream) {
+  Geo g; TrainWs t;
+  int rc = make_geo(B, H, W, g);
+  if (rc) return rc;
+  SVS_REQUIRE(params && grads && mix && (part == 0 || part == 1), "svs_unet_train_bwd_part: bad arguments");
+  if ((rc = check_train_ws("svs_unet_train_bwd_part", g, ws, ws_bytes, t))) return rc;
+  return train_backward_impl(view_params(params), grads, mix, drop, g, t, stream, part == 0 ? 1 : 2);
 }

@@ -407,13 +407,46 @@ class UNet(nn.Module):
         self._grads_clean = False
         return loss[0]
 
+    def fwd_bwd_overlapped(self, mix, voc, loss_scale, grad_sync):
+        """Same result as fwd_bwd, as three library calls so that the gradient exchange overlaps the backward:
+        forward + loss; backward of the decoder half (its gradients occupy the tail of the flat buffer) followed
+        at once by an asynchronous all-reduce of that tail; backward of the encoder half; all-reduce of the head.
+        Returns (loss, [work handles])."""
+        mix, voc = self._check_input(mix), self._check_input(voc)
+        B, _, H, W = mix.shape
+        ws = self._workspace("train", B, H, W)
+        self._drop = self._drop_masks(B)
+        self._generation += 1
+        self._attach_grads()
+        assert self._grads_clean, "overlapped exchange needs zero_grad() first (it overwrites the flat gradient buffer)"
+        loss = torch.empty(1, dtype=torch.float32, device=mix.device)
+        L = lib()
+        check(L.svs_unet_train_fwd_loss(ptr(self._flat), ptr(self._bn_flat), ptr(self._nbt_flat), ptr(mix), ptr(voc), ptr(self._drop),
+                                        B, H, W, float(loss_scale), None, ptr(loss), ptr(ws), ws.numel(), _lib.stream_ptr()),
+              "svs_unet_train_fwd_loss")
+        split = int(L.svs_unet_param_offset(24))           # first decoder tensor (deconv1.weight)
+        handles = []
+        for part, sl in ((0, self._gflat[split:]), (1, self._gflat[:split])):
+            check(L.svs_unet_train_bwd_part(ptr(self._flat), ptr(self._gflat), ptr(mix), ptr(self._drop), B, H, W, part, ptr(ws),
+                                            ws.numel(), _lib.stream_ptr()), "svs_unet_train_bwd_part")
+            handles.append(grad_sync.reduce_async(sl))
+        self._grads_clean = False
+        return loss[0], handles
+
     def train_step(self, mix, voc, loss_scale=1.0, grad_sync=None):
         """zero_grad + fwd_bwd + (optional gradient all-reduce) + Adam: the whole of train.py:271-300
-        (L1 terms).  `grad_sync(flat_grad)` is the data-parallel hook (see parallel.py)."""
+        (L1 terms).  `grad_sync` is the data-parallel hook (parallel.GradAllReduce): with `reduce_async` the
+        exchange of the decoder half overlaps the encoder half's backward, otherwise `grad_sync(flat_grad)`
+        runs after the backward."""
         self.optim.zero_grad()
-        loss = self.fwd_bwd(mix, voc, loss_scale)
-        if grad_sync is not None:
-            grad_sync(self._gflat)
+        if grad_sync is not None and getattr(grad_sync, "overlap", False):
+            loss, handles = self.fwd_bwd_overlapped(mix, voc, loss_scale, grad_sync)
+            for h in handles:
+                h.wait()
+        else:
+            loss = self.fwd_bwd(mix, voc, loss_scale)
+            if grad_sync is not None:
+                grad_sync(self._gflat)
         self.optim.step()
         return loss
 

@@ -2,9 +2,12 @@
 (tiles are independent; the training step has exactly one exchange, the gradient sum).
 
 The reference is single-process (it has no distributed code at all), so the semantics are chosen here:
-  * gradients: ONE all-reduce (SUM, fp32) of the model's flat 9,823,313-element gradient buffer per step
-    over RCCL/xGMI (`backend="nccl"` is RCCL on ROCm); the 1/world mean is folded into the fused Adam
-    kernel (`FusedAdam.grad_scale`), so no extra pass over the gradients;
+  * gradients: all-reduce (SUM, fp32) of the model's flat 9,823,313-element gradient buffer over RCCL/xGMI
+    (`backend="nccl"` is RCCL on ROCm) in TWO pieces that follow the backward pass: the decoder half (tensors
+    24..45, 5.45 M floats, produced first) is reduced on RCCL's stream while the encoder half (4.37 M floats)
+    is still being computed, then the encoder half.  xGMI is point-to-point, so fewer, larger messages beat many
+    small buckets; two is what the dependency structure of the backward pass offers.  The 1/world mean is folded
+    into the fused Adam kernel (`FusedAdam.grad_scale`), so there is no extra pass over the gradients;
   * BatchNorm: per-GPU batch statistics (what DistributedDataParallel over the reference would do);
     running statistics stay per rank and rank 0's are the ones checkpointed;
   * Dropout2d: the rank is folded into the mask counter, so shards draw independent masks;
@@ -25,13 +28,21 @@ def shard_range(n_items: int, rank: int, world: int):
 
 
 class GradAllReduce:
-    """`grad_sync` hook for `UNet.train_step`: sums the flat gradient buffer across the group."""
+    """`grad_sync` hook for `UNet.train_step`.  `overlap=True` (default): `reduce_async(slice)` is called
+    right after each half of the backward is enqueued; `overlap=False`: `__call__(flat)` after the backward."""
 
-    def __init__(self, model, group=None):
+    def __init__(self, model, group=None, overlap: bool = True):
         self.group = group
         self.world = dist.get_world_size(group)
+        self.overlap = overlap
         model.optim.grad_scale = 1.0 / self.world
         model.rank = dist.get_rank(group)
+
+    def reduce_async(self, grad_slice: torch.Tensor):
+        """Starts the SUM all-reduce of a contiguous slice of the flat gradient buffer; returns the work handle.
+        RCCL waits (on its own stream) for the kernels already enqueued on the current stream, and `wait()` makes
+        the current stream wait for the reduction -- neither blocks the host."""
+        return dist.all_reduce(grad_slice, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def __call__(self, flat_grad: torch.Tensor):
         dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group)

@@ -243,3 +243,42 @@ def test_train_step_learns_and_checkpoint_roundtrip(tmp_path, report):
     model.eval(), m2.eval()
     with torch.no_grad():
         assert torch.equal(model(mix[:2]).cpu(), m2(mix[:2]).cpu())
+
+
+def test_split_backward_equals_fused(report):
+    """The overlapped data-parallel path (forward+loss, decoder-half backward, encoder-half backward as three
+    library calls with the exchange hook in between) must produce the fused call's gradients bit for bit."""
+    B = 3
+    mix_np, voc_np = synth.tiles(B, first_tile=700)
+    mix, voc = torch.from_numpy(mix_np).to(DEV), torch.from_numpy(voc_np).to(DEV)
+    masks = [torch.from_numpy(m) for m in synth.dropout_masks(B, seed=11, step=0)]
+
+    class FakeSync:
+        overlap = True
+
+        def __init__(self):
+            self.calls = []
+
+        def reduce_async(self, sl):
+            self.calls.append((sl.data_ptr(), sl.numel()))
+
+            class H:
+                def wait(self_inner):
+                    return None
+            return H()
+
+    a, b = make_model(trained_stats=False).train(), make_model(trained_stats=False).train()
+    a.set_dropout_masks(masks), b.set_dropout_masks(masks)
+    a.optim.zero_grad(), b.optim.zero_grad()
+    la = a.fwd_bwd(mix, voc, loss_scale=166.66)
+    sync = FakeSync()
+    lb, handles = b.fwd_bwd_overlapped(mix, voc, 166.66, sync)
+    assert la.item() == lb.item() and len(handles) == 2
+    assert torch.equal(a._gflat, b._gflat)
+    split = int(_lib.lib().svs_unet_param_offset(24))
+    assert sync.calls == [(b._gflat.data_ptr() + 4 * split, b._n_params - split), (b._gflat.data_ptr(), split)]
+    assert torch.equal(a._bn_flat, b._bn_flat)
+    # and a whole step through train_step with the hook
+    l2 = b.train_step(mix, voc, loss_scale=166.66, grad_sync=sync)
+    l1 = a.train_step(mix, voc, loss_scale=166.66)
+    assert l1.item() == l2.item() and torch.equal(a._flat, b._flat)

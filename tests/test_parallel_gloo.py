@@ -51,7 +51,12 @@ def _worker(rank, world, port, out):
         _, g = _shard_grads(rank)
         out[f"g{rank}"] = g.clone()
         model._gflat.copy_(g)
-        sync(model._gflat)
+        # the overlapped form: two asynchronous pieces (decoder half first), as UNet.fwd_bwd_overlapped issues them
+        split = sum(n for _, n in model._param_spans[:24])
+        assert sync.overlap
+        handles = [sync.reduce_async(model._gflat[split:]), sync.reduce_async(model._gflat[:split])]
+        for h in handles:
+            h.wait()
         if rank == 0:
             out["flat"] = model._flat.clone()
             out["summed"] = model._gflat.clone()
