@@ -2,7 +2,7 @@
 // apply (+ LeakyReLU/ReLU + Dropout2d), BatchNorm backward, the L1 mask loss, Adam, weight packing,
 // eval-mode BN folding, synthetic data.  All tensors are fp32 NHWC (pixel-major), read and written
 // as float4 by C/4 adjacent lanes per pixel.  Bound: HBM (each tensor once per pass).
-#include "common.h"
+#include "internal.h"
 
 // ------------------------------------------------------------------------------------------------
 // per-channel block reduction shared by bn_stats (sum x, sum x^2) and bn_bwd (sum dz, sum dz*xhat)
@@ -150,23 +150,46 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   coef[2 * C + c] = (float)(sx / (double)P);
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnCtx p, const float* __restrict__ coef, float* __restrict__ d_raw) {
+// d_raw = k * (dz - mean(dz) - xhat * mean(dz*xhat)); when `partial` is given the block also leaves the per-channel
+// sum of its d_raw values there ([blk][2][C] layout, first half) -- that sum over all blocks is the gradient of the
+// conv bias in front of this BatchNorm (the reference gets it from autograd; true value 0, what remains is
+// rounding noise), obtained here without a second pass over d_raw.
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnCtx p, const float* __restrict__ coef, float* __restrict__ d_raw,
+                                                           float* __restrict__ partial, long pix_per_block) {
+  __shared__ f32x4 red[256];
   const int G = p.C >> 2;
-  const long total = p.P * G;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int cg = (int)(i % G);
-    const long pix = i / G;
+  const int t = threadIdx.x;
+  const int cg = t % G, pl = t / G, PL = 256 / G;
+  const long p0 = (long)blockIdx.x * pix_per_block;
+  long p1 = p0 + pix_per_block;
+  if (p1 > p.P) p1 = p.P;
+  const f32x4 inv4 = *(const f32x4*)(p.invstd + cg * 4);
+  const f32x4 k4 = *(const f32x4*)(coef + cg * 4);
+  const f32x4 mean4 = *(const f32x4*)(p.mean + cg * 4);
+  const f32x4 beta4 = *(const f32x4*)(p.beta + cg * 4);
+  const f32x4 c1 = *(const f32x4*)(coef + p.C + cg * 4);
+  const f32x4 c2 = *(const f32x4*)(coef + 2 * p.C + cg * 4);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (long pix = p0 + pl; pix < p1; pix += PL) {
     const f32x4 x = *(const f32x4*)(p.raw + pix * p.ldr + cg * 4);
     f32x4 dz = *(const f32x4*)(p.dy + pix * p.lddy + cg * 4);
     if (p.drop) dz *= *(const f32x4*)(p.drop + (pix / p.pps) * p.C + cg * 4);
-    const f32x4 inv4 = *(const f32x4*)(p.invstd + cg * 4);
-    const f32x4 k4 = *(const f32x4*)(coef + cg * 4);
-    const f32x4 xm = x - *(const f32x4*)(p.mean + cg * 4);
-    const f32x4 z = xm * k4 + *(const f32x4*)(p.beta + cg * 4);
+    const f32x4 xm = x - mean4;
+    const f32x4 z = xm * k4 + beta4;
 #pragma unroll
     for (int k = 0; k < 4; ++k) dz[k] = z[k] > 0.f ? dz[k] : dz[k] * p.slope;
-    const f32x4 r = k4 * (dz - *(const f32x4*)(coef + p.C + cg * 4) - (xm * inv4) * *(const f32x4*)(coef + 2 * p.C + cg * 4));
+    const f32x4 r = k4 * (dz - c1 - (xm * inv4) * c2);
     *(f32x4*)(d_raw + pix * p.C + cg * 4) = r;
+    acc += r;
+  }
+  if (partial) {
+    red[t] = acc;
+    __syncthreads();
+    if (t < G) {
+      f32x4 a = red[t];
+      for (int j = 1; j < PL; ++j) a += red[j * G + t];
+      *(f32x4*)(partial + (long)blockIdx.x * 2 * p.C + t * 4) = a;
+    }
   }
 }
 
@@ -223,10 +246,24 @@ extern "C" int svs_bn_act_apply(const float* raw, int64_t ldr, int64_t P, int C,
   return SVS_OK;
 }
 
+int svs_bn_bwd_run(const float* dy, long lddy, const float* raw, long ldr, long P, int C, long pixels_per_sample,
+                   const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, float slope,
+                   const float* drop, float* d_raw, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes,
+                   hipStream_t stream);
+__global__ void channel_sum_finalize_kernel(const float* __restrict__ partial, int nblk, int C, float* out);
+
 extern "C" int svs_bn_bwd(const float* dy, int64_t lddy, const float* raw, int64_t ldr, int64_t P, int C,
                           int64_t pixels_per_sample, const float* gamma, const float* beta, const float* save_mean,
                           const float* save_invstd, float slope, const float* drop, float* d_raw, float* dgamma,
                           float* dbeta, void* ws, size_t ws_bytes, hipStream_t stream) {
+  return svs_bn_bwd_run(dy, lddy, raw, ldr, P, C, pixels_per_sample, gamma, beta, save_mean, save_invstd, slope, drop, d_raw,
+                        dgamma, dbeta, nullptr, ws, ws_bytes, stream);
+}
+
+int svs_bn_bwd_run(const float* dy, long lddy, const float* raw, long ldr, long P, int C, long pixels_per_sample,
+                   const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, float slope,
+                   const float* drop, float* d_raw, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes,
+                   hipStream_t stream) {
   int rc = check_bn("svs_bn_bwd", raw, ldr, P, C);
   if (rc) return rc;
   SVS_REQUIRE(dy && d_raw && lddy >= C && lddy % 4 == 0 && svs_aligned16(dy) && svs_aligned16(d_raw), "svs_bn_bwd: bad gradient view");
@@ -242,8 +279,14 @@ extern "C" int svs_bn_bwd(const float* dy, int64_t lddy, const float* raw, int64
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C / 4), dim3(256), 0, stream, (const float*)partial, nb, (long)P, C,
                      gamma, save_invstd, dgamma, dbeta, coef);
   SVS_CHECK_LAUNCH("bn_bwd_finalize");
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(P * (C / 4))), dim3(256), 0, stream, p, (const float*)coef, d_raw);
+  // the apply pass reuses the partial buffer of the reduce pass (already consumed by the finalize kernel)
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nb), dim3(256), 0, stream, p, (const float*)coef, d_raw, dbias ? partial : nullptr,
+                     (P + nb - 1) / nb);
   SVS_CHECK_LAUNCH("bn_bwd_apply");
+  if (dbias) {
+    hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3(C / 4), dim3(256), 0, stream, (const float*)partial, nb, C, dbias);
+    SVS_CHECK_LAUNCH("channel_sum_finalize");
+  }
   return SVS_OK;
 }
 
@@ -487,6 +530,59 @@ extern "C" int svs_pack_weight_parity(const float* w, float* wp, int C, int N, h
   SVS_REQUIRE(w && wp && N > 0 && C > 0, "svs_pack_weight_parity: bad arguments");
   hipLaunchKernelGGL(pack_parity_kernel, dim3(grid_for((long)N * C * 25)), dim3(256), 0, stream, w, wp, C, N);
   SVS_CHECK_LAUNCH("pack_parity");
+  return SVS_OK;
+}
+
+// All weight packings of a step in ONE launch (10 layers x 2 layouts used to be 20 launches of ~8 us each).
+// One block per output-channel row; the row's C x 25 weights go through LDS so that both the global reads
+// (25- or 25*C-float runs) and the global writes (C-float runs) are contiguous.
+__global__ __launch_bounds__(256) void pack_all_kernel(SvsPackJobs jobs) {
+  __shared__ float tile[512 * 25];
+  int ji = 0;
+  while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.j[ji + 1].first_block) ++ji;
+  const SvsPackJob jb = jobs.j[ji];
+  const int n = blockIdx.x - jb.first_block;
+  const int C = jb.C, N = jb.N, tot = C * 25;
+  if (jb.kind == 0) {           // gather: w[n][c][tap] -> wp[n][tap][c]
+    const float* src = jb.w + (long)n * tot;
+    for (int e = threadIdx.x; e < tot; e += 256) tile[e] = src[e];
+    __syncthreads();
+    float* dst = jb.wp + (long)n * tot;
+    for (int e = threadIdx.x; e < tot; e += 256) {
+      const int tap = e / C, c = e - tap * C;
+      dst[e] = tile[c * 25 + tap];
+    }
+  } else {                      // parity: w[c][n][tap] -> wp[p][n][th][tw][c]
+    for (int e = threadIdx.x; e < tot; e += 256) {
+      const int c = e / 25, tap = e - c * 25;
+      tile[e] = jb.w[((long)c * N + n) * 25 + tap];
+    }
+    __syncthreads();
+    const long NC = (long)N * C;
+#pragma unroll
+    for (int par = 0; par < 4; ++par) {
+      const int ph = par >> 1, pw = par & 1, ntw = 3 - pw, ntaps = (3 - ph) * ntw;
+      const int poff = (par == 0) ? 0 : (par == 1) ? 9 : (par == 2) ? 15 : 21;
+      float* dst = jb.wp + poff * NC + (long)n * ntaps * C;
+      for (int e = threadIdx.x; e < ntaps * C; e += 256) {
+        const int t2 = e / C, c = e - t2 * C;
+        const int th = t2 / ntw, tw = t2 - th * ntw;
+        dst[e] = tile[c * 25 + (ph + 2 * th) * 5 + pw + 2 * tw];
+      }
+    }
+  }
+}
+
+int svs_pack_all_run(SvsPackJobs& jobs, hipStream_t stream) {
+  int blocks = 0;
+  for (int i = 0; i < jobs.n; ++i) {
+    SVS_REQUIRE(jobs.j[i].C <= 512 && jobs.j[i].w && jobs.j[i].wp, "svs_pack_all: bad job %d", i);
+    jobs.j[i].first_block = blocks;
+    blocks += jobs.j[i].N;
+  }
+  if (!blocks) return SVS_OK;
+  hipLaunchKernelGGL(pack_all_kernel, dim3(blocks), dim3(256), 0, stream, jobs);
+  SVS_CHECK_LAUNCH("pack_all");
   return SVS_OK;
 }
 

@@ -29,3 +29,14 @@ int svs_sigmoid_bwd_run(const float* mask, const float* dmask, long n, float* d_
 
 // out[g][i] = sum over the g-th chunk of `per` consecutive slabs of slab[z][i]   (i < n, g < groups)
 int svs_reduce_slabs_run(const float* slab, int nslab, int per, int groups, long n, float* out, hipStream_t stream);
+
+// one launch for several weight packings: kind 0 = gather packing of w[N][C][25], kind 1 = parity packing of w[C][N][25]
+struct SvsPackJob { const float* w; float* wp; int N, C, kind, first_block; };
+struct SvsPackJobs { SvsPackJob j[20]; int n; };
+int svs_pack_all_run(SvsPackJobs& jobs, hipStream_t stream);
+
+// svs_bn_bwd plus (dbias != NULL) the per-channel sum of d_raw = gradient of the conv bias in front of the BatchNorm
+int svs_bn_bwd_run(const float* dy, long lddy, const float* raw, long ldr, long P, int C, long pixels_per_sample,
+                   const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, float slope,
+                   const float* drop, float* d_raw, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes,
+                   hipStream_t stream);

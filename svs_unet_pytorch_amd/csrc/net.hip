@@ -204,10 +204,12 @@ extern "C" int svs_unet_prepare_eval(const float* params, const float* bn_buffer
   int rc;
   // conv1: C == 1, the gather packing is torch's layout; deconv6: N == 1, kernel reads torch's layout
   SVS_HIP(hipMemcpyAsync(blob + L.wp[0], v.w[0], param_numel(0) * sizeof(float), hipMemcpyDeviceToDevice, stream));
-  for (int k = 2; k <= 6; ++k)
-    if ((rc = svs_pack_weight_gather(v.w[k - 1], blob + L.wp[k - 1], CH[k], CH[k - 1], stream))) return rc;
-  for (int j = 0; j < 5; ++j)
-    if ((rc = svs_pack_weight_parity(v.w[6 + j], blob + L.wp[6 + j], DEC_C[j], DEC_N[j], stream))) return rc;
+  {
+    SvsPackJobs jobs{};
+    for (int k = 2; k <= 6; ++k) jobs.j[jobs.n++] = SvsPackJob{v.w[k - 1], blob + L.wp[k - 1], CH[k], CH[k - 1], 0, 0};
+    for (int j = 0; j < 5; ++j) jobs.j[jobs.n++] = SvsPackJob{v.w[6 + j], blob + L.wp[6 + j], DEC_N[j], DEC_C[j], 1, 0};
+    if ((rc = svs_pack_all_run(jobs, stream))) return rc;
+  }
   SVS_HIP(hipMemcpyAsync(blob + L.wp[11], v.w[11], param_numel(44) * sizeof(float), hipMemcpyDeviceToDevice, stream));
   SVS_HIP(hipMemcpyAsync(blob + L.bias6, v.b[11], sizeof(float), hipMemcpyDeviceToDevice, stream));
   for (int l = 0; l < 11; ++l) {
@@ -371,13 +373,18 @@ static int train_forward_impl(const ParamView& v, float* bn_buffers, int64_t* nb
   const int B = g.B;
   int rc;
   // weight packings for this step (weights change every optimiser step)
-  for (int k = 2; k <= 6; ++k) {
-    if ((rc = svs_pack_weight_gather(v.w[k - 1], t.wfwd[k - 1], CH[k], CH[k - 1], stream))) return rc;
-    if ((rc = svs_pack_weight_parity(v.w[k - 1], t.wbwd[k - 1], CH[k], CH[k - 1], stream))) return rc;   // conv (N,C,..) read as (in=N,out=C)
-  }
-  for (int j = 0; j < 5; ++j) {
-    if ((rc = svs_pack_weight_parity(v.w[6 + j], t.wfwd[6 + j], DEC_C[j], DEC_N[j], stream))) return rc;
-    if ((rc = svs_pack_weight_gather(v.w[6 + j], t.wbwd[6 + j], DEC_C[j], DEC_N[j], stream))) return rc;  // convT (C,N,..) read as (n=C,c=N)
+  {
+    SvsPackJobs jobs{};
+    auto add = [&](const float* w, float* wp, int N, int C, int kind) { jobs.j[jobs.n++] = SvsPackJob{w, wp, N, C, kind, 0}; };
+    for (int k = 2; k <= 6; ++k) {
+      add(v.w[k - 1], t.wfwd[k - 1], CH[k], CH[k - 1], 0);          // conv forward: gather packing
+      add(v.w[k - 1], t.wbwd[k - 1], CH[k - 1], CH[k], 1);          // conv bwd-data: (N,C,..) read as (in=N,out=C): one row per C
+    }
+    for (int j = 0; j < 5; ++j) {
+      add(v.w[6 + j], t.wfwd[6 + j], DEC_N[j], DEC_C[j], 1);        // convT forward: parity packing, one row per output channel
+      add(v.w[6 + j], t.wbwd[6 + j], DEC_C[j], DEC_N[j], 0);        // convT bwd-data: (C,N,..) read as (n=C,c=N)
+    }
+    if ((rc = svs_pack_all_run(jobs, stream))) return rc;
   }
   // encoder: conv (+bias) -> raw; batch stats; BN + LeakyReLU -> second half of cat[k]
   for (int k = 1; k <= 6; ++k) {
@@ -434,11 +441,11 @@ static int train_backward_impl(const ParamView& v, float* grads, const float* mi
   for (int j = 4; j >= 0; --j) {
     const int lin = 6 - j, lout = 5 - j, l = 6 + j, N = DEC_N[j], C = DEC_C[j];
     const float* x = (j == 0) ? t.c6 : t.cat[lin];
-    rc = svs_bn_bwd(t.dcat[lout], 2 * CH[lout], t.raw_d[j], N, g.P[lout], N, (long)g.h[lout] * g.w[lout], v.gamma[l], v.beta[l],
-                    t.mean[l], t.invstd[l], 0.f, drop ? drop + drop_off[j] : nullptr, t.d_raw, G(24 + 4 * j + 2), G(24 + 4 * j + 3),
-                    t.bnws, t.bnws_bytes, stream);
+    rc = svs_bn_bwd_run(t.dcat[lout], 2 * CH[lout], t.raw_d[j], N, g.P[lout], N, (long)g.h[lout] * g.w[lout], v.gamma[l], v.beta[l],
+                        t.mean[l], t.invstd[l], 0.f, drop ? drop + drop_off[j] : nullptr, t.d_raw, G(24 + 4 * j + 2), G(24 + 4 * j + 3),
+                        G(24 + 4 * j + 1), t.bnws, t.bnws_bytes, stream);          // + bias gradient (sum of d_raw)
     if (rc) return rc;
-    if ((rc = svs_dec_block_bwd_weight(x, C, B, g.h[lin], g.w[lin], C, t.d_raw, N, g.h[lout], g.w[lout], N, G(24 + 4 * j), G(24 + 4 * j + 1),
+    if ((rc = svs_dec_block_bwd_weight(x, C, B, g.h[lin], g.w[lin], C, t.d_raw, N, g.h[lout], g.w[lout], N, G(24 + 4 * j), nullptr,
                                        t.scratch, t.scratch_bytes, stream))) return rc;
     float* dx = (j == 0) ? t.dc6 : t.dcat[lin];
     if ((rc = svs_dec_block_bwd_data(t.d_raw, N, B, g.h[lout], g.w[lout], N, t.wbwd[l], dx, C, g.h[lin], g.w[lin], C, 0,
@@ -451,12 +458,12 @@ static int train_backward_impl(const ParamView& v, float* grads, const float* mi
     const int l = k - 1, N = CH[k], C = CH[k - 1];
     const float* dy = (k == 6) ? t.dc6 : t.dcat[k] + CH[k];
     const long lddy = (k == 6) ? 512 : 2 * CH[k];
-    rc = svs_bn_bwd(dy, lddy, t.raw_e[k], N, g.P[k], N, (long)g.h[k] * g.w[k], v.gamma[l], v.beta[l], t.mean[l], t.invstd[l],
-                    LEAKY, nullptr, t.d_raw, G(4 * l + 2), G(4 * l + 3), t.bnws, t.bnws_bytes, stream);
+    rc = svs_bn_bwd_run(dy, lddy, t.raw_e[k], N, g.P[k], N, (long)g.h[k] * g.w[k], v.gamma[l], v.beta[l], t.mean[l], t.invstd[l],
+                        LEAKY, nullptr, t.d_raw, G(4 * l + 2), G(4 * l + 3), G(4 * l + 1), t.bnws, t.bnws_bytes, stream);
     if (rc) return rc;
     const float* x = (k == 1) ? mix : t.cat[k - 1] + C;
     const long ldx = (k == 1) ? 1 : 2 * C;
-    if ((rc = svs_enc_block_bwd_weight(t.d_raw, N, B, g.h[k], g.w[k], N, x, ldx, g.h[k - 1], g.w[k - 1], C, G(4 * l), G(4 * l + 1),
+    if ((rc = svs_enc_block_bwd_weight(t.d_raw, N, B, g.h[k], g.w[k], N, x, ldx, g.h[k - 1], g.w[k - 1], C, G(4 * l), nullptr,
                                        t.scratch, t.scratch_bytes, stream))) return rc;
     if (k >= 2) {
       // gradient of the skip half of cat[k-1]: add to what decoder (7-k)'s bwd_data left there
