@@ -26,6 +26,17 @@ struct WgradArgs {
   int ws_shift, hs_shift; // log2 of Ws / Hs when they are powers of two, else -1
 };
 
+template <int T> __device__ __forceinline__ void load_vec(const float* p, float (&f)[T]);
+template <> __device__ __forceinline__ void load_vec<4>(const float* p, float (&f)[4]) {
+  const f32x4 v = *(const f32x4*)p; f[0] = v[0]; f[1] = v[1]; f[2] = v[2]; f[3] = v[3];
+}
+template <> __device__ __forceinline__ void load_vec<2>(const float* p, float (&f)[2]) {
+  const float2 v = *(const float2*)p; f[0] = v.x; f[1] = v.y;
+}
+template <int T> __device__ __forceinline__ void store_vec(float* p, const float (&f)[T]);
+template <> __device__ __forceinline__ void store_vec<4>(float* p, const float (&f)[4]) { *(f32x4*)p = (f32x4){f[0], f[1], f[2], f[3]}; }
+template <> __device__ __forceinline__ void store_vec<2>(float* p, const float (&f)[2]) { *(float2*)p = make_float2(f[0], f[1]); }
+
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void wgrad_gemm_kernel(WgradArgs p) {
   constexpr int TM = BM / WM / 16;
@@ -144,12 +155,13 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(WgradArgs p) {
     if (more) load_tile(pk + 16);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
+      // Interleaved tiles: MFMA tile i of this wave owns the rows {TM*r + i : r = 0..15} (and tile j the columns
+      // {TN*c + j}), so the TM (TN) operands a lane needs for one k are CONTIGUOUS in the m- (n-) major LDS rows
+      // and come with one ds_read_b128 / b64 instead of TM (TN) ds_read_b32.
       float fa[TM], fb[TN];
       const int kr = 4 * q + k;
-#pragma unroll
-      for (int i = 0; i < TM; ++i) fa[i] = As[buf][kr * LDA + wm * (TM * 16) + i * 16 + lrow];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) fb[j] = Bs[buf][kr * LDB + wn * (TN * 16) + j * 16 + lrow];
+      load_vec<TM>(&As[buf][kr * LDA + wm * (TM * 16) + TM * lrow], fa);
+      load_vec<TN>(&Bs[buf][kr * LDB + wn * (TN * 16) + TN * lrow], fb);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -160,16 +172,20 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(WgradArgs p) {
     __syncthreads();
   }
 
+  // C/D map of the 16x16 MFMA (col = lane & 15, row = 4*(lane>>4) + reg) through the interleaving above:
+  // tile (i, j), reg r holds row TM*(4q+r) + i, column TN*lrow + j -> the TN columns of a lane are adjacent
   float* slab = p.slab + (long)blockIdx.z * p.Cs * Ntot;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int cs = cs0 + wm * (TM * 16) + i * 16 + q * 4 + r;
+      const int cs = cs0 + wm * (TM * 16) + TM * (4 * q + r) + i;
+      const int n = n0 + wn * (TN * 16) + TN * lrow;
+      if (n < Ntot) {          // Ntot and n are multiples of TN (Cl % 4 == 0), so the vector is all in or all out
+        float v[TN];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * (TN * 16) + j * 16 + lrow;
-        if (n < Ntot) slab[(long)cs * Ntot + n] = acc[i][j][r];
+        for (int j = 0; j < TN; ++j) v[j] = acc[i][j][r];
+        store_vec<TN>(&slab[(long)cs * Ntot + n], v);
       }
     }
 }

@@ -86,7 +86,32 @@ def main():
         tot[1] += best[1]
         print(f"{name:18s} A {best[0] * 1e3:7.1f} us {gflop / best[0]:6.1f} TF   B {best[1] * 1e3:7.1f} us {gflop / best[1]:6.1f} TF   B/A time {best[1] / best[0]:.3f}  maxdiff {same:.1e}",
               flush=True)
-    print(f"TOTAL A {tot[0] * 1e3:.1f} us   B {tot[1] * 1e3:.1f} us   B/A {tot[1] / tot[0]:.3f}")
+    print(f"TOTAL conv A {tot[0] * 1e3:.1f} us   B {tot[1] * 1e3:.1f} us   B/A {tot[1] / tot[0]:.3f}")
+    if not a.wgrad:
+        return
+    tot = [0.0, 0.0]
+    wg = [(f"conv{k}.bwd_weight", hw[k], CH[k], hw[k - 1], CH[k - 1]) for k in range(2, 7)]
+    wg += [(f"deconv{j + 1}.bwd_weight", hw[6 - j], c, hw[5 - j], n) for j, (c, n) in enumerate(DEC)]
+    for name, (hs, wsz), cs, (hl, wl), cl in wg:
+        sm = torch.rand((B, hs, wsz, cs), device=dev) - 0.5
+        lg = torch.rand((B, hl, wl, cl), device=dev) - 0.5
+        dws = [torch.empty(cs * cl * 25, device=dev) for _ in libs]
+        runs = [lambda L=L, dw=dw: L.svs_enc_block_bwd_weight(sm.data_ptr(), cs, B, hs, wsz, cs, lg.data_ptr(), cl, hl, wl, cl, dw.data_ptr(),
+                                                              None, ws.data_ptr(), ws.numel(), S()) for L, dw in zip(libs, dws)]
+        for r in runs:
+            assert r() == 0
+        torch.cuda.synchronize()
+        same = ((dws[0] - dws[1]).abs().max() / dws[0].abs().max()).item()
+        best = [1e9, 1e9]
+        for _ in range(3):
+            for i, r in enumerate(runs):
+                best[i] = min(best[i], timeit(r))
+        gflop = 2.0 * B * hs * wsz * cs * cl * 25 / 1e9
+        tot[0] += best[0]
+        tot[1] += best[1]
+        print(f"{name:20s} A {best[0] * 1e3:7.1f} us {gflop / best[0]:6.1f} TF   B {best[1] * 1e3:7.1f} us {gflop / best[1]:6.1f} TF   B/A time {best[1] / best[0]:.3f}  reldiff {same:.1e}",
+              flush=True)
+    print(f"TOTAL wgrad A {tot[0] * 1e3:.1f} us   B {tot[1] * 1e3:.1f} us   B/A {tot[1] / tot[0]:.3f}")
 
 
 if __name__ == "__main__":
