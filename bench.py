@@ -36,42 +36,63 @@ FWD_GFLOP_PER_TILE = 1.507328
 TRAIN_GFLOP_PER_TILE = 4.5088768
 
 
-def layer_table(B, H=512, W=128):
-    """(name, kind, geometry, algorithmic GFLOP) of every MFMA layer of one forward at batch B."""
+def gemm_calls(B, mode, H=512, W=128):
+    """Every MFMA GEMM call of one step at batch B: (name, kind, args, GFLOP).  kind 0 = gather GEMM, 1 = parity
+    GEMM, 2 = weight gradient (include/svs_hip.h: svs_describe_plan).  Eval has the 10 forward calls only."""
     hw = [(H, W)]
     for _ in range(6):
         hw.append(((hw[-1][0] + 1) // 2, (hw[-1][1] + 1) // 2))
-    rows = []
+    calls = []
     for k in range(2, 7):
         (h, w), (ho, wo) = hw[k - 1], hw[k]
         c, n = ENC_CHANNELS[k - 1], ENC_CHANNELS[k]
-        rows.append((f"conv{k}", "enc", (B, h, w, c, n, ho, wo), 2.0 * B * ho * wo * n * c * 25 / 1e9))
+        gf = 2.0 * B * ho * wo * n * c * 25 / 1e9
+        calls.append((f"conv{k}.fwd", 0, (h, w, c, ho, wo, n), gf))
+        if mode == "train":
+            calls.append((f"conv{k}.bwd_data", 1, (ho, wo, n, h, w, c), gf))
+            calls.append((f"conv{k}.bwd_weight", 2, (ho, wo, n, h, w, c), gf))
     for j in range(5):
         (h, w), (ho, wo) = hw[6 - j], hw[5 - j]
         c, n = DEC_IO[j]
-        rows.append((f"deconv{j + 1}", "dec", (B, h, w, c, n, ho, wo), 2.0 * B * h * w * n * c * 25 / 1e9))
-    return rows
+        gf = 2.0 * B * h * w * n * c * 25 / 1e9
+        calls.append((f"deconv{j + 1}.fwd", 1, (h, w, c, ho, wo, n), gf))
+        if mode == "train":
+            calls.append((f"deconv{j + 1}.bwd_data", 0, (ho, wo, n, h, w, c), gf))
+            calls.append((f"deconv{j + 1}.bwd_weight", 2, (h, w, c, ho, wo, n), gf))
+    return calls
 
 
-def time_layers(B, reps=10):
-    """Per-layer forward kernels timed with HIP events on torch's current stream (the stream every launch of
-    the library is given).  Returns [(name, kernel family, ms, GFLOP)]."""
+def time_gemm_calls(B, mode, reps=10, only_kernel=None):
+    """Each GEMM call of a step, timed with HIP events on torch's current stream (the stream every launch of the
+    library is given), attributed to the kernel the planner picks (svs_describe_plan -> the name rocprofv3 shows).
+    A call = the GEMM kernel plus, where the planner splits K, its fixed-order slab reduction.
+    Returns [(name, kernel, ksplit, ms, GFLOP)]."""
+    import ctypes
     L = _lib.lib()
     dev = "cuda"
+    ws = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+    buf = ctypes.create_string_buffer(128)
     out = []
-    for name, kind, (b, h, w, c, n, ho, wo), gflop in layer_table(B):
-        x = torch.rand((b, h, w, c), device=dev)
-        wp = (torch.rand(n * c * 25, device=dev) - 0.5) * 0.05
-        sc, sh = torch.rand(n, device=dev) + 0.5, torch.rand(n, device=dev) - 0.5
-        y = torch.empty((b, ho, wo, n), device=dev)
-        if kind == "enc":
-            ws = torch.empty(int(L.svs_enc_block_workspace_bytes(b, h, w, c, n)) + 4096, dtype=torch.uint8, device=dev)
-            run = lambda: L.svs_enc_block_fwd(x.data_ptr(), c, b, h, w, c, wp.data_ptr(), None, sc.data_ptr(), sh.data_ptr(),
-                                              0.2, y.data_ptr(), n, n, 0, ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+    for name, kind, (h, w, c, ho, wo, n), gflop in gemm_calls(B, mode):
+        x = torch.rand((B, h, w, c), device=dev) - 0.5
+        if kind == 2:
+            other = torch.rand((B, ho, wo, n), device=dev) - 0.5
+            dw = torch.empty(c * n * 25, device=dev)
+            ks = L.svs_describe_plan(2, B, h, w, c, 0, 0, n, buf, 128)
+            run = lambda: L.svs_enc_block_bwd_weight(x.data_ptr(), c, B, h, w, c, other.data_ptr(), n, ho, wo, n, dw.data_ptr(), None,
+                                                     ws.data_ptr(), ws.numel(), _lib.stream_ptr())
         else:
-            ws = torch.empty(int(L.svs_dec_block_workspace_bytes(b, h, w, c, ho, wo, n)) + 4096, dtype=torch.uint8, device=dev)
-            run = lambda: L.svs_dec_block_fwd(x.data_ptr(), c, b, h, w, c, wp.data_ptr(), None, sc.data_ptr(), sh.data_ptr(),
-                                              0.0, y.data_ptr(), n, ho, wo, n, 0, ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+            wp = (torch.rand(n * c * 25, device=dev) - 0.5) * 0.05
+            y = torch.empty((B, ho, wo, n), device=dev)
+            ks = L.svs_describe_plan(kind, B, h, w, c, ho, wo, n, buf, 128)
+            if kind == 0:
+                run = lambda: L.svs_enc_block_fwd(x.data_ptr(), c, B, h, w, c, wp.data_ptr(), None, None, None, 0.0, y.data_ptr(), n, n, 0,
+                                                  ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+            else:
+                run = lambda: L.svs_dec_block_fwd(x.data_ptr(), c, B, h, w, c, wp.data_ptr(), None, None, None, 0.0, y.data_ptr(), n, ho, wo,
+                                                  n, 0, ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+        if only_kernel is not None and buf.value.decode() != only_kernel:
+            continue
         for _ in range(3):
             _lib.check(run(), name)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -80,8 +101,19 @@ def time_layers(B, reps=10):
             run()
         e1.record()
         torch.cuda.synchronize()
-        out.append((name, "conv_gemm_kernel<GATHER>" if kind == "enc" else "conv_gemm_kernel<PARITY>", e0.elapsed_time(e1) / reps, gflop))
+        out.append((name, buf.value.decode(), ks, e0.elapsed_time(e1) / reps, gflop))
     return out
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the rocprofv3 --pmc passes kept under profiles/ (FETCH_SIZE doubled per
+    the gfx950 correction of MI355X_MICROARCH.md, WRITE_SIZE as is); None when no summary covers the kernel."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(kernel, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
 
 
 def cpu_baseline(mode, seconds_budget=20.0):
@@ -201,19 +233,29 @@ def main():
         }
         if world == 1:
             if not args.no_layers:
-                layers = time_layers(B)
+                calls = time_gemm_calls(B, args.mode)
                 fam = {}
-                for name, family, ms, gf in layers:
-                    a = fam.setdefault(family, [0.0, 0.0, 0])
-                    a[0] += ms; a[1] += gf; a[2] += 1
-                dom = max(fam, key=lambda f: fam[f][0])
-                ms, gf, cnt = fam[dom]
+                for name, kernel, ks, ms, gf in calls:
+                    e = fam.setdefault(kernel, [0.0, 0.0, 0])
+                    e[0] += ms; e[1] += gf; e[2] += 1
+                dom = max(fam, key=lambda k: fam[k][0])
+                # the dominant kernel ALONE (its fixed-order slab reduction is a separate kernel in the rocprofv3
+                # summary): same calls again with the reduction skipped, so that avg_launch_ms is comparable with
+                # the summary's average duration of that kernel
+                os.environ["SVS_SKIP_REDUCE"] = "1"
+                alone = [c for c in time_gemm_calls(B, args.mode, only_kernel=dom)]
+                os.environ.pop("SVS_SKIP_REDUCE")
+                ms, gf, cnt = sum(c[3] for c in alone), sum(c[4] for c in alone), len(alone)
                 ach = gf / ms            # GFLOP / ms = TFLOP/s
                 res["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                                   "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                                   "launches": cnt, "avg_launch_ms": round(ms / cnt, 4),
-                                   "algorithmic_gflop_per_launch": round(gf / cnt, 3)}
-                res["layers"] = {name: {"ms": round(ms, 4), "tflops": round(gf / ms, 2)} for name, _, ms, gf in layers}
+                                   "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(dom),
+                                   "launches_per_step": cnt, "avg_launch_ms": round(ms / cnt, 4),
+                                   "algorithmic_gflop_per_launch": round(gf / cnt, 3),
+                                   "note": "HIP events on the launch stream around each launch of this kernel in one step "
+                                           "(slab reductions excluded); algorithmic FLOPs = 2*M*N*K of the layer"}
+                res["kernels"] = {k: {"calls": v[2], "ms": round(v[0], 4), "tflops": round(v[1] / v[0], 2)} for k, v in fam.items()}
+                res["layers"] = {name: {"kernel": kernel, "ksplit": ks, "ms": round(ms, 4), "tflops": round(gf / ms, 2)}
+                                 for name, kernel, ks, ms, gf in calls}
             if not args.no_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline(args.mode)
         print(json.dumps(res), flush=True)

@@ -115,6 +115,12 @@ int svs_dec_block_bwd_weight(const float* x, int64_t ldx, int B, int H, int W, i
                              const float* dy, int64_t lddy, int Ho, int Wo, int N,
                              float* dw, float* db, void* ws, size_t ws_bytes, hipStream_t stream);
 
+/* Which kernel (name as rocprofv3 prints it) and K-split the planner uses for a block call of the given geometry:
+ * kind 0 = gather GEMM (svs_enc_block_fwd / svs_dec_block_bwd_data), 1 = parity GEMM (svs_dec_block_fwd /
+ * svs_enc_block_bwd_data), 2 = weight gradient (H,W,C: the strided image, N: channels of the windowed image).
+ * Lets bench.py attribute its live HIP-event timings to the kernels of the rocprofv3 summary. */
+int svs_describe_plan(int kind, int B, int H, int W, int C, int Ho, int Wo, int N, char* buf, size_t buflen);
+
 /* ---------------------------------------------------------------------------------------------
  * Training-mode BatchNorm2d + activation (+ Dropout2d) -- model.py:49-50, 81-83 in .train().
  * raw is the (P = B*H*W, C) conv output.  svs_bn_stats writes per-workgroup partial sums,

@@ -45,6 +45,7 @@ _SIGS = {
     "svs_block_bwd_weight_workspace_bytes": (Z, [I, I, I, I, I]),
     "svs_enc_block_bwd_weight": (I, [P, L, I, I, I, I, P, L, I, I, I, P, P, P, Z, P]),
     "svs_dec_block_bwd_weight": (I, [P, L, I, I, I, I, P, L, I, I, I, P, P, P, Z, P]),
+    "svs_describe_plan": (I, [I, I, I, I, I, I, I, I, C.c_char_p, Z]),
     "svs_bn_workspace_bytes": (Z, [L, I]),
     "svs_bn_stats": (I, [P, L, L, I, P, Z, P]),
     "svs_bn_finalize": (I, [P, L, I, F, F, P, P, P, P, P, P]),

@@ -534,7 +534,7 @@ int svs_conv_gemm_run(int mode, const float* x, long ldx, int B, int H, int W, i
   }
   rc = (mode == MODE_GATHER) ? launch_conv_gemm<MODE_GATHER>(a, pl, stream) : launch_conv_gemm<MODE_PARITY>(a, pl, stream);
   if (rc) return rc;
-  if (pl.ksplit > 1) {
+  if (pl.ksplit > 1 && !getenv("SVS_SKIP_REDUCE")) {      // (the switch lets bench.py time the GEMM kernel alone)
     const long total4 = P * N / 4;
     int grid = (int)((total4 + 255) / 256);
     if (grid > 2048) grid = 2048;
@@ -554,4 +554,23 @@ size_t svs_conv_gemm_workspace(int mode, int B, int H, int W, int C, int Ho, int
   ConvPlan pl = plan_conv(mode, Mmax, N, nkt_min);
   if (pl.ksplit <= 1) return 0;
   return (size_t)pl.ksplit * B * Ho * Wo * N * sizeof(float);
+}
+
+// Name (as rocprofv3 prints it) and K-split of the kernel the planner picks for a conv GEMM -- bench.py groups its
+// live per-layer timings by this name so that they can be matched against the rocprofv3 kernel statistics.
+int svs_conv_gemm_describe(int mode, int B, int H, int W, int C, int Ho, int Wo, int N, long ldx, char* buf, size_t n) {
+  long Mmax;
+  int nkt_min;
+  if (mode == MODE_GATHER) { Mmax = (long)B * Ho * Wo; nkt_min = 25 * (C / 16); }
+  else { Mmax = (long)B * ((Ho + 1) / 2) * ((Wo + 1) / 2); nkt_min = 4 * (C / 16); }
+  int direct = 0;
+  if (Mmax >= 16384 && ((long)B * H * W * ldx + 4L * (W + 2) * ldx) * 4 < (1L << 31)) {
+    if (N == 16) direct = 1;
+    else if (N == 32 && mode == MODE_PARITY && C >= 128) direct = 1;
+  }
+  if (direct) { snprintf(buf, n, "conv_direct_kernel<%d, 4, %d>", mode, N / 16); return 1; }
+  static const int wm[10] = {2, 2, 4, 4, 1, 2, 2, 4, 4, 4}, wn[10] = {2, 2, 1, 1, 4, 2, 2, 1, 1, 1};
+  const ConvPlan pl = plan_conv(mode, Mmax, N, nkt_min);
+  snprintf(buf, n, "conv_gemm_kernel<%d, %d, %d, %d, %d>", mode, pl.BM, pl.BN, wm[pl.cfg], wn[pl.cfg]);
+  return pl.ksplit;
 }

@@ -272,6 +272,7 @@ int svs_wgrad_gemm_run(const float* s, long lds, int B, int Hs, int Ws, int Cs, 
     default: hipLaunchKernelGGL((wgrad_gemm_kernel<32, 128, 1, 4>), grid, dim3(256), 0, stream, a); break;
   }
   SVS_CHECK_LAUNCH("wgrad_gemm");
+  if (getenv("SVS_SKIP_REDUCE")) return SVS_OK;             // lets bench.py time the GEMM kernel alone
   const long n = (long)Cs * 25 * Cl;
   const float* slabs = (const float*)ws;
   int nslab = pl.ksplit;
@@ -287,4 +288,10 @@ int svs_wgrad_gemm_run(const float* s, long lds, int B, int Hs, int Ws, int Cs, 
                      Cl, dw);
   SVS_CHECK_LAUNCH("wgrad_reduce");
   return SVS_OK;
+}
+
+int svs_wgrad_gemm_describe(int B, int Hs, int Ws, int Cs, int Cl, char* buf, size_t n) {
+  const WgradPlan pl = plan_wgrad(B, Hs, Ws, Cs, Cl);
+  snprintf(buf, n, "wgrad_gemm_kernel<%d, %d, %d, %d>", pl.BM, pl.BN, pl.cfg == 0 ? 2 : 1, pl.cfg == 0 ? 2 : 4);
+  return pl.ksplit;
 }

@@ -40,3 +40,6 @@ int svs_bn_bwd_run(const float* dy, long lddy, const float* raw, long ldr, long 
                    const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, float slope,
                    const float* drop, float* d_raw, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes,
                    hipStream_t stream);
+
+int svs_conv_gemm_describe(int mode, int B, int H, int W, int C, int Ho, int Wo, int N, long ldx, char* buf, size_t n);
+int svs_wgrad_gemm_describe(int B, int Hs, int Ws, int Cs, int Cl, char* buf, size_t n);

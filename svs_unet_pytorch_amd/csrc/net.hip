@@ -108,6 +108,14 @@ extern "C" int svs_dec_block_bwd_weight(const float* x, int64_t ldx, int B, int 
   return svs_channel_sum_run(dy, lddy, (long)B * Ho * Wo, N, db, ws, ws_bytes, stream);
 }
 
+// kind 0: gather GEMM (enc fwd / dec bwd_data), 1: parity GEMM (dec fwd / enc bwd_data), 2: weight-gradient GEMM
+// (then H,W,C = the strided image S and N = channels of the windowed image).  Returns the K-split.
+extern "C" int svs_describe_plan(int kind, int B, int H, int W, int C, int Ho, int Wo, int N, char* buf, size_t buflen) {
+  if (!buf || !buflen) return SVS_ERR_INVALID;
+  if (kind == 2) return svs_wgrad_gemm_describe(B, H, W, C, N, buf, buflen);
+  return svs_conv_gemm_describe(kind == 1 ? SVS_MODE_PARITY : SVS_MODE_GATHER, B, H, W, C, Ho, Wo, N, C, buf, buflen);
+}
+
 // ---------------------------------------------------------------------------------------------
 // network description
 // ---------------------------------------------------------------------------------------------
