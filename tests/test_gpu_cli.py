@@ -87,3 +87,27 @@ def test_pipeline_end_to_end(tmp_path, report, monkeypatch):
         assert report(f"cli to_wave {name} (interior)", np.abs(y - want)[1024:-1024].max(), 5e-5)
     with pytest.raises(Exception):
         svs_data.main(["--src", str(pred_dir), "--tar", str(wav_dir), "--direction", "to_wave"])    # data.py:118
+
+
+def test_streaming_end_to_end(report):
+    """BASELINE configs[4] in fp32: waveform -> STFT -> U-Net -> mask -> iSTFT without leaving the GPU, against the
+    same chain built from the three oracles; 44.1 kHz-length stereo input (the sample rate only labels the file)."""
+    from svs_unet_pytorch_amd.model import UNet
+    from svs_unet_pytorch_amd.streaming import separate_waveform
+    state = synth.closed_form_state()
+    model = UNet()
+    model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in state.items()})
+    model.to("cuda").eval()
+    n = 44100 * 3
+    y = np.stack([synth.audio(n, 10), synth.audio(n, 11)])
+    got = separate_waveform(model, torch.from_numpy(y).to("cuda")).cpu().numpy()
+    T = 1 + n // 768
+    assert got.shape == (2, 768 * (T - 1))
+    st = uo.to_torch_state(state)
+    for ch in range(2):
+        spec, phase = so.to_spec(y[ch], y[ch])
+        with torch.no_grad():
+            pred = to.separate(spec, lambda t: uo.forward(st, torch.from_numpy(t)).numpy())
+        want = so.to_wave(pred, phase)
+        assert abs(np.abs(got[ch]).max() - 0.9) <= 1e-5
+        assert report(f"streaming separation channel {ch} (interior)", np.abs(got[ch] - want)[1024:-1024].max(), 1e-4)
