@@ -158,6 +158,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="tiles per GPU (default 64 train / 16 eval)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-layers", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even with one rank")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -170,7 +171,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or (args.force_dist and "RANK" in os.environ)     # --force-dist: rehearse the RCCL path with 1 rank
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -188,7 +190,7 @@ def main():
     grad_sync = None
     if args.mode == "train":
         model.train()
-        if world > 1:
+        if use_dist:
             from svs_unet_pytorch_amd.parallel import GradAllReduce
             grad_sync = GradAllReduce(model, dist.group.WORLD)
         step = lambda: model.train_step(mix, voc, loss_scale=ALPHA_L1, grad_sync=grad_sync)

@@ -86,32 +86,48 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs p) {
   const long Kw = (long)ntaps * p.C;   // weight row length
 
   // ---- per-thread staging rows -----------------------------------------------------------------
+  // fp32 MFMA and VALU instructions do not overlap on a SIMD (tools/mfma_valu_probe.hip: time ~ MFMA cycles +
+  // VALU cycles whatever the occupancy), so the K-loop spends as few VALU instructions per MFMA as possible:
+  // operands are fetched with buffer loads -- per row a 32-bit byte offset computed ONCE, per tile a scalar
+  // (SGPR) offset for the tap / channel chunk, and a 25-bit per-row validity mask decided ONCE; an invalid row
+  // (zero padding, M tail, unused B row) is pointed past num_records and the hardware range check returns
+  // zeros.  Per A row and tile that is a bit test and a select -- no address arithmetic, no branches.
   const int chunk = t & 3;
-  int a_h[RA], a_w[RA];             // GATHER: 2oh-2, 2ow-2 ; PARITY: a+1, c+1
-  long a_img[RA];                   // pixel index of (b, 0, 0)
-  bool a_ok[RA];
+  constexpr unsigned OOB = 0x80000000u;           // >= num_records of both descriptors
+  unsigned a_voff[RA], a_mask[RA];
 #pragma unroll
   for (int r = 0; r < RA; ++r) {
     const int row = (t >> 2) + 64 * r;
     const long m = m0 + row;
-    a_ok[r] = (row < BM) && (m < M);
-    const long mm = a_ok[r] ? m : 0;
+    const bool ok = (row < BM) && (m < M);
+    const long mm = ok ? m : 0;
     const int wq = (int)(mm % Wa);
     const long tmp = mm / Wa;
     const int hq = (int)(tmp % Ha);
-    const int b = (int)(tmp / Ha);
-    a_img[r] = (long)b * p.H * p.W;
-    if (MODE == MODE_GATHER) { a_h[r] = 2 * hq - 2; a_w[r] = 2 * wq - 2; }
-    else { a_h[r] = hq + 1; a_w[r] = wq + 1; }
+    const long b = tmp / Ha;
+    const int h0 = (MODE == MODE_GATHER) ? 2 * hq : hq;      // anchor pixel of the row
+    const int w0 = (MODE == MODE_GATHER) ? 2 * wq : wq;
+    a_voff[r] = ok ? (unsigned)((((b * p.H + h0) * p.W + w0) * p.ldx + chunk * 4) * 4) : OOB;
+    unsigned mask = 0;
+    for (int th = 0; th < nth; ++th)
+      for (int tw = 0; tw < ntw; ++tw) {
+        const int ih = (MODE == MODE_GATHER) ? h0 - 2 + th : h0 + 1 - th;
+        const int iw = (MODE == MODE_GATHER) ? w0 - 2 + tw : w0 + 1 - tw;
+        if (ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) mask |= 1u << (th * ntw + tw);
+      }
+    a_mask[r] = mask;
   }
-  const float* b_row[RB];
-  bool b_ok[RB];
+  unsigned b_voff[RB];
 #pragma unroll
   for (int r = 0; r < RB; ++r) {
     const int row = (t >> 2) + 64 * r;
-    b_ok[r] = row < BN;
-    b_row[r] = wp + (long)(n0 + (b_ok[r] ? row : 0)) * Kw + chunk * 4;
+    b_voff[r] = (row < BN) ? (unsigned)(((long)(n0 + row) * Kw + chunk * 4) * 4) : OOB;
   }
+  // base pointer shifted so that every per-tile scalar offset is >= 0: GATHER tap (th,tw) reads pixel
+  // anchor + (th-2, tw-2) = [anchor - (2,2)] + (th,tw); PARITY reads anchor + (1-th, 1-tw) = [anchor - (1,1)] + (2-th, 2-tw)
+  const long shift = (MODE == MODE_GATHER) ? (2L * p.W + 2) * p.ldx : (1L * p.W + 1) * p.ldx;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x - shift), 0, OOB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wp, 0, OOB, 0x00020000);
 
   f32x4 ra[RA], rb[RB];
   // (tap row, tap column, channel chunk) of the next tile to load; tiles are loaded in order from kt_begin
@@ -124,37 +140,31 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs p) {
     l_tw = tap - l_th * ntw;
   }
   auto load_tile = [&](int) {
-    const int c0 = l_cc << 4;
-    const int th = l_th, tw = l_tw;
-    const long koff = (long)(th * ntw + tw) * p.C + c0;      // column of this tile in the packed weight rows
+    const int th = l_th, tw = l_tw, tap = th * ntw + tw;
+    const int pix = (MODE == MODE_GATHER) ? th * p.W + tw : (2 - th) * p.W + (2 - tw);
+    const int soff_a = (int)((pix * p.ldx + (l_cc << 4)) * 4);
+    const int soff_b = (int)(((long)tap * p.C + (l_cc << 4)) * 4);
     if (p.tap_inner) { if (++l_tw == ntw) { l_tw = 0; if (++l_th == nth) { l_th = 0; ++l_cc; } } }
     else { if (++l_cc == cpt) { l_cc = 0; if (++l_tw == ntw) { l_tw = 0; ++l_th; } } }
 #pragma unroll
     for (int r = 0; r < RA; ++r) {
-      const int ih = (MODE == MODE_GATHER) ? a_h[r] + th : a_h[r] - th;
-      const int iw = (MODE == MODE_GATHER) ? a_w[r] + tw : a_w[r] - tw;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (a_ok[r] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
-        v = *(const f32x4*)(p.x + (a_img[r] + (long)ih * p.W + iw) * p.ldx + c0 + chunk * 4);
-      ra[r] = v;
+      const unsigned vo = ((a_mask[r] >> tap) & 1u) ? a_voff[r] : OOB;
+      ra[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)vo, soff_a, 0));
     }
 #pragma unroll
-    for (int r = 0; r < RB; ++r) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (b_ok[r]) v = *(const f32x4*)(b_row[r] + koff);
-      rb[r] = v;
-    }
+    for (int r = 0; r < RB; ++r)
+      rb[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (int)b_voff[r], soff_b, 0));
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf) {       // unconditional when the tile height is a multiple of 64 rows (no exec-mask branches)
 #pragma unroll
     for (int r = 0; r < RA; ++r) {
       const int row = (t >> 2) + 64 * r;
-      if (row < BM) *(f32x4*)(&As[buf][row * 16 + swz(row, chunk) * 4]) = ra[r];
+      if (BM % 64 == 0 || row < BM) *(f32x4*)(&As[buf][row * 16 + swz(row, chunk) * 4]) = ra[r];
     }
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
       const int row = (t >> 2) + 64 * r;
-      if (row < BN) *(f32x4*)(&Bs[buf][row * 16 + swz(row, chunk) * 4]) = rb[r];
+      if (BN % 64 == 0 || row < BN) *(f32x4*)(&Bs[buf][row * 16 + swz(row, chunk) * 4]) = rb[r];
     }
   };
 
@@ -488,6 +498,9 @@ int svs_conv_gemm_run(int mode, const float* x, long ldx, int B, int H, int W, i
     Mmax = (long)B * ((Ho + 1) / 2) * ((Wo + 1) / 2);
     nkt_min = 4 * (C / 16);
   }
+  // operands are addressed with 32-bit byte offsets (buffer loads): each view must stay below 2 GiB
+  SVS_REQUIRE(((long)B * H * W * ldx + 4L * (W + 2) * ldx) * 4 < (1L << 31) && (long)N * C * 25 * 4 < (1L << 31),
+              "%s: input view of %ld bytes needs 64-bit offsets; split the batch", who, (long)B * H * W * ldx * 4);
   ConvPlan pl = plan_conv(mode, Mmax, N, nkt_min);
   ConvGemmArgs a{};
   a.x = x; a.ldx = ldx; a.B = B; a.H = H; a.W = W; a.C = C; a.wp = wp;
