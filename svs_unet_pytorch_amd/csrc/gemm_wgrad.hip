@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(WgradArgs p) {
 
   // (b, i, j) of each B row's pixel, advanced by 16 pixels per K-tile with 32-bit arithmetic
   // (a 64-bit divide per row per tile used to cost more VALU time than the tile's MFMAs)
-  int bj[RB], bi[RB]; long bimg[RB];
+  int bj[RB], bi[RB]; unsigned bimg[RB];            // bimg: pixel index of (b, 0, 0) in L (< 2^31, checked on the host)
 #pragma unroll
   for (int r = 0; r < RB; ++r) {
     const unsigned pix = (unsigned)(p_begin + bk[r]);
@@ -91,9 +91,9 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(WgradArgs p) {
     bj[r] = (int)(pix - row * (unsigned)p.Ws);
     const unsigned img = row / (unsigned)p.Hs;
     bi[r] = (int)(row - img * (unsigned)p.Hs);
-    bimg[r] = (long)img * p.Hl * p.Wl;
+    bimg[r] = img * (unsigned)(p.Hl * p.Wl);
   }
-  const long img_stride = (long)p.Hl * p.Wl;
+  const unsigned img_stride = (unsigned)(p.Hl * p.Wl);
   auto advance = [&]() {
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
@@ -103,28 +103,35 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(WgradArgs p) {
       unsigned nb;
       if (p.hs_shift >= 0) { nb = i >> p.hs_shift; i &= (unsigned)p.Hs - 1u; }
       else { nb = i / (unsigned)p.Hs; i -= nb * (unsigned)p.Hs; }
-      bj[r] = (int)j; bi[r] = (int)i; bimg[r] += (long)nb * img_stride;
+      bj[r] = (int)j; bi[r] = (int)i; bimg[r] += nb * img_stride;
     }
   };
 
+  // Operands come through buffer loads (few VALU instructions per tile -- fp32 MFMA and VALU do not overlap on a
+  // SIMD): A rows have a fixed per-thread byte offset plus a per-tile scalar offset; B rows a 32-bit offset from
+  // the incremental (b,i,j); a row outside the image / the split / the matrix is pointed past num_records and
+  // reads zeros.
+  constexpr unsigned OOB = 0x80000000u;
+  unsigned a_voff[RA];
+#pragma unroll
+  for (int r = 0; r < RA; ++r) a_voff[r] = aok[r] ? (unsigned)(((long)ak[r] * p.lds + cs0 + ac[r] * 4) * 4) : OOB;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.s + p_begin * p.lds), 0, OOB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void*)p.l, 0, OOB, 0x00020000);
   f32x4 ra[RA], rb[RB];
   auto load_tile = [&](long pk) {      // must be called with pk advancing by 16 from p_begin
+    const int soff_a = (int)((pk - p_begin) * p.lds * 4);
+    const int left = (int)(p_end - pk);          // rows of this tile inside the split (16 except in its last tile)
 #pragma unroll
     for (int r = 0; r < RA; ++r) {
-      const long pix = pk + ak[r];
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (aok[r] && pix < p_end) v = *(const f32x4*)(p.s + pix * p.lds + cs0 + ac[r] * 4);
-      ra[r] = v;
+      const unsigned vo = ak[r] < left ? a_voff[r] : OOB;
+      ra[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)vo, soff_a, 0));
     }
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (bok[r] && pk + bk[r] < p_end) {
-        const int ih = 2 * bi[r] - 2 + bkh[r], iw = 2 * bj[r] - 2 + bkw[r];
-        if ((unsigned)ih < (unsigned)p.Hl && (unsigned)iw < (unsigned)p.Wl)
-          v = *(const f32x4*)(p.l + (bimg[r] + (long)ih * p.Wl + iw) * p.ldl + bcl[r]);
-      }
-      rb[r] = v;
+      const int ih = 2 * bi[r] - 2 + bkh[r], iw = 2 * bj[r] - 2 + bkw[r];
+      const bool ok = bok[r] && bk[r] < left && (unsigned)ih < (unsigned)p.Hl && (unsigned)iw < (unsigned)p.Wl;
+      const unsigned vo = ((bimg[r] + (unsigned)(ih * p.Wl + iw)) * (unsigned)p.ldl + (unsigned)bcl[r]) * 4u;
+      rb[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rl, (int)(ok ? vo : OOB), 0, 0));
     }
     advance();
   };
@@ -265,6 +272,8 @@ int svs_wgrad_gemm_run(const float* s, long lds, int B, int Hs, int Ws, int Cs, 
   auto log2_or_neg = [](int v) { int s = 0; while ((1 << s) < v) ++s; return (1 << s) == v ? s : -1; };
   a.ws_shift = log2_or_neg(Ws); a.hs_shift = log2_or_neg(Hs);
   SVS_REQUIRE((long)B * Hs * Ws < (1L << 31), "%s: pixel count exceeds 2^31", who);
+  SVS_REQUIRE((long)B * Hl * Wl * ldl * 4 < (1L << 31) && (long)(pl.pps + 16) * lds * 4 < (1L << 31),
+              "%s: operand views need 64-bit offsets; split the batch", who);
   dim3 grid((unsigned)(Cs / pl.BM), (unsigned)((25 * Cl + pl.BN - 1) / pl.BN), (unsigned)pl.ksplit);
   switch (pl.cfg) {
     case 0: hipLaunchKernelGGL((wgrad_gemm_kernel<128, 128, 2, 2>), grid, dim3(256), 0, stream, a); break;
