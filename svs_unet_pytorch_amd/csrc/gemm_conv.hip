@@ -140,7 +140,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs p) {
     l_tw = tap - l_th * ntw;
   }
   auto load_tile = [&](int) {
-    const int th = l_th, tw = l_tw, tap = th * ntw + tw;
+    const int th = l_th, tw = l_tw;
+    const int tap = th * ntw + tw;
     const int pix = (MODE == MODE_GATHER) ? th * p.W + tw : (2 - th) * p.W + (2 - tw);
     const int soff_a = (int)((pix * p.ldx + (l_cc << 4)) * 4);
     const int soff_b = (int)(((long)tap * p.C + (l_cc << 4)) * 4);

@@ -282,3 +282,29 @@ def test_split_backward_equals_fused(report):
     l2 = b.train_step(mix, voc, loss_scale=166.66, grad_sync=sync)
     l1 = a.train_step(mix, voc, loss_scale=166.66)
     assert l1.item() == l2.item() and torch.equal(a._flat, b._flat)
+
+
+def test_eval_forward_is_graph_capturable(report):
+    """Every launch goes to the caller's stream and nothing synchronises or allocates, so a whole forward can be
+    captured into a hipGraph (torch.cuda.CUDAGraph) and replayed."""
+    model = make_model().eval()
+    mix_np, _ = synth.tiles(4, first_tile=900)
+    static_in = torch.from_numpy(mix_np).to(DEV)
+    with torch.no_grad():
+        want = model(static_in).clone()                  # also builds the prepared weights and the workspace
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s), torch.no_grad():
+        model(static_in)                                 # warm-up on the capture stream
+        torch.cuda.current_stream().synchronize()
+        with torch.cuda.graph(g, stream=s):
+            static_out = model(static_in)
+    torch.cuda.current_stream().wait_stream(s)
+    mix2, _ = synth.tiles(4, first_tile=950)
+    static_in.copy_(torch.from_numpy(mix2))
+    g.replay()
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        want2 = model(static_in)
+    assert torch.equal(static_out, want2) and not torch.equal(want, want2)
