@@ -16,11 +16,11 @@ size_t svs_wgrad_gemm_workspace(int B, int Hs, int Ws, int Cs, int Cl);
 
 int svs_conv_c1_run(const float* x, int B, int H, int W, const float* w, const float* bias, const float* scale,
                     const float* shift, float slope, float* y, long ldy, int N, int accumulate, hipStream_t stream,
-                    const char* who);
+                    const char* who, long half = 0);
 int svs_deconv_to1_run(const float* x, long ldx, int B, int H, int W, int C, const float* w, const float* bias,
-                       float* y, int Ho, int Wo, int apply_sigmoid, hipStream_t stream, const char* who);
+                       float* y, int Ho, int Wo, int apply_sigmoid, hipStream_t stream, const char* who, long half = 0);
 int svs_wgrad_c1_run(const float* s, long lds, int B, int Hs, int Ws, int Cs, const float* l, int Hl, int Wl,
-                     float* dw, void* ws, size_t ws_bytes, hipStream_t stream, const char* who);
+                     float* dw, void* ws, size_t ws_bytes, hipStream_t stream, const char* who, long half = 0);
 size_t svs_wgrad_c1_workspace(int B, int Hs, int Ws, int Cs);
 
 int svs_channel_sum_run(const float* x, long ldx, long P, int C, float* out, void* ws, size_t ws_bytes, hipStream_t stream);

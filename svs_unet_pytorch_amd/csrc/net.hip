@@ -176,6 +176,18 @@ static int make_geo(int B, int H, int W, Geo& g) {
   return SVS_OK;
 }
 
+// One channel half of the level-k concat buffer (which: 0 = decoder output, 1 = encoder/skip output).
+// Levels 2..5 interleave the halves inside a pixel (ld = 2*ch, a half is >= 128 B so accesses are whole lines).
+// Level 1 has 16-channel halves (64 B): interleaved, every access of a half would touch half a 128-byte line and
+// drag the other half through the caches, so level 1 is PLANAR -- two dense (P, 16) planes back to back; the three
+// kernels that need all 32 channels of a pixel (deconv6 forward / weight gradient / data gradient) take the plane
+// distance as `half` (special.hip: chan_off).
+struct View { float* p; long ld; };
+static View cat_half(float* const* cat, const Geo& g, int k, int which) {
+  if (k == 1) return View{cat[1] + (long)which * g.P[1] * 16, 16};
+  return View{cat[k] + (long)which * CH[k], 2L * CH[k]};
+}
+
 // bump allocator over the caller's workspace (every block 256-byte aligned)
 struct Arena {
   char* base; size_t used;
@@ -266,10 +278,10 @@ extern "C" int svs_unet_forward_eval(const void* prepared, const float* mix, flo
   const float* blob = (const float*)prepared;
   // encoder (model.py:176-181): BN folded, LeakyReLU(0.2) in the epilogue
   for (int k = 1; k <= 6; ++k) {
-    const float* x = (k == 1) ? mix : e.cat[k - 1] + CH[k - 1];
-    const long ldx = (k == 1) ? 1 : 2 * CH[k - 1];
-    float* y = (k == 6) ? e.c6 : e.cat[k] + CH[k];
-    const long ldy = (k == 6) ? 512 : 2 * CH[k];
+    const View xi = (k == 1) ? View{const_cast<float*>(mix), 1} : cat_half(e.cat, g, k - 1, 1);
+    const View yo = (k == 6) ? View{e.c6, 512} : cat_half(e.cat, g, k, 1);
+    const float* x = xi.p; const long ldx = xi.ld;
+    float* y = yo.p; const long ldy = yo.ld;
     rc = svs_enc_block_fwd(x, ldx, B, g.h[k - 1], g.w[k - 1], CH[k - 1], blob + L.wp[k - 1], nullptr,
                            blob + L.scale[k - 1], blob + L.shift[k - 1], LEAKY, y, ldy, CH[k], 0, e.scratch, e.scratch_bytes, stream);
     if (rc) return rc;
@@ -278,13 +290,15 @@ extern "C" int svs_unet_forward_eval(const void* prepared, const float* mix, flo
   for (int j = 0; j < 5; ++j) {
     const int lin = 6 - j, lout = 5 - j;
     const float* x = (j == 0) ? e.c6 : e.cat[lin];
+    const View yo = cat_half(e.cat, g, lout, 0);
     rc = svs_dec_block_fwd(x, DEC_C[j], B, g.h[lin], g.w[lin], DEC_C[j], blob + L.wp[6 + j], nullptr, blob + L.scale[6 + j],
-                           blob + L.shift[6 + j], 0.f, e.cat[lout], 2 * CH[lout], g.h[lout], g.w[lout], DEC_N[j], 0,
+                           blob + L.shift[6 + j], 0.f, yo.p, yo.ld, g.h[lout], g.w[lout], DEC_N[j], 0,
                            e.scratch, e.scratch_bytes, stream);
     if (rc) return rc;
   }
   // deconv6 + sigmoid (model.py:198-200)
-  return svs_out_block_fwd(e.cat[1], 32, B, g.h[1], g.w[1], 32, blob + L.wp[11], blob + L.bias6, mask, H, W, 1, stream);
+  return svs_deconv_to1_run(e.cat[1], 16, B, g.h[1], g.w[1], 32, blob + L.wp[11], blob + L.bias6, mask, H, W, 1, stream,
+                            "svs_unet_forward_eval", g.P[1] * 16);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -396,8 +410,8 @@ static int train_forward_impl(const ParamView& v, float* bn_buffers, int64_t* nb
   }
   // encoder: conv (+bias) -> raw; batch stats; BN + LeakyReLU -> second half of cat[k]
   for (int k = 1; k <= 6; ++k) {
-    const float* x = (k == 1) ? mix : t.cat[k - 1] + CH[k - 1];
-    const long ldx = (k == 1) ? 1 : 2 * CH[k - 1];
+    const View xi = (k == 1) ? View{const_cast<float*>(mix), 1} : cat_half(t.cat, g, k - 1, 1);
+    const float* x = xi.p; const long ldx = xi.ld;
     const float* wp = (k == 1) ? v.w[0] : t.wfwd[k - 1];
     rc = svs_enc_block_fwd(x, ldx, B, g.h[k - 1], g.w[k - 1], CH[k - 1], wp, v.b[k - 1], nullptr, nullptr, 0.f, t.raw_e[k],
                            CH[k], CH[k], 0, t.scratch, t.scratch_bytes, stream);
@@ -407,8 +421,8 @@ static int train_forward_impl(const ParamView& v, float* bn_buffers, int64_t* nb
     if ((rc = svs_bn_finalize(t.bnws, g.P[k], CH[k], BN_EPS, BN_MOMENTUM, bn_buffers ? bn_buffers + svs_unet_buffer_offset(l, 0) : nullptr,
                               bn_buffers ? bn_buffers + svs_unet_buffer_offset(l, 1) : nullptr, nbt ? nbt + l : nullptr,
                               t.mean[l], t.invstd[l], stream))) return rc;
-    float* y = (k == 6) ? t.c6 : t.cat[k] + CH[k];
-    const long ldy = (k == 6) ? 512 : 2 * CH[k];
+    const View yo = (k == 6) ? View{t.c6, 512} : cat_half(t.cat, g, k, 1);
+    float* y = yo.p; const long ldy = yo.ld;
     if ((rc = svs_bn_act_apply(t.raw_e[k], CH[k], g.P[k], CH[k], (long)g.h[k] * g.w[k], v.gamma[l], v.beta[l], t.mean[l],
                                t.invstd[l], LEAKY, nullptr, y, ldy, stream))) return rc;
   }
@@ -424,11 +438,13 @@ static int train_forward_impl(const ParamView& v, float* bn_buffers, int64_t* nb
     if ((rc = svs_bn_finalize(t.bnws, g.P[lout], DEC_N[j], BN_EPS, BN_MOMENTUM, bn_buffers ? bn_buffers + svs_unet_buffer_offset(l, 0) : nullptr,
                               bn_buffers ? bn_buffers + svs_unet_buffer_offset(l, 1) : nullptr, nbt ? nbt + l : nullptr,
                               t.mean[l], t.invstd[l], stream))) return rc;
+    const View yo = cat_half(t.cat, g, lout, 0);
     if ((rc = svs_bn_act_apply(t.raw_d[j], DEC_N[j], g.P[lout], DEC_N[j], (long)g.h[lout] * g.w[lout], v.gamma[l], v.beta[l],
-                               t.mean[l], t.invstd[l], 0.f, dp, t.cat[lout], 2 * CH[lout], stream))) return rc;
+                               t.mean[l], t.invstd[l], 0.f, dp, yo.p, yo.ld, stream))) return rc;
     if (dp) dp += (long)B * DEC_N[j];
   }
-  return svs_out_block_fwd(t.cat[1], 32, B, g.h[1], g.w[1], 32, v.w[11], v.b[11], mask, g.h[0], g.w[0], 1, stream);
+  return svs_deconv_to1_run(t.cat[1], 16, B, g.h[1], g.w[1], 32, v.w[11], v.b[11], mask, g.h[0], g.w[0], 1, stream,
+                            "svs_unet_train_forward", g.P[1] * 16);
 }
 
 // parts: bit 0 = decoder half (deconv6..deconv1: gradients of parameter tensors 24..45, produced FIRST),
@@ -441,15 +457,20 @@ static int train_backward_impl(const ParamView& v, float* grads, const float* mi
   auto G = [&](int idx) { return grads + svs_unet_param_offset(idx); };
   if (parts & 1) {
   // deconv6 (model.py:109,198): dw, db, dx -> dcat[1]
-  if ((rc = svs_dec_block_bwd_weight(t.cat[1], 32, B, g.h[1], g.w[1], 32, t.d_logit, 1, g.h[0], g.w[0], 1, G(44), G(45), t.scratch, t.scratch_bytes, stream))) return rc;
-  if ((rc = svs_dec_block_bwd_data(t.d_logit, 1, B, g.h[0], g.w[0], 1, v.w[11], t.dcat[1], 32, g.h[1], g.w[1], 32, 0, t.scratch, t.scratch_bytes, stream))) return rc;
+  const long half1 = g.P[1] * 16;     // level 1 is planar (cat_half)
+  if ((rc = svs_wgrad_c1_run(t.cat[1], 16, B, g.h[1], g.w[1], 32, t.d_logit, g.h[0], g.w[0], G(44), t.scratch, t.scratch_bytes, stream,
+                             "deconv6 bwd_weight", half1))) return rc;
+  if ((rc = svs_sum_run(t.d_logit, g.P[0], G(45), t.scratch, t.scratch_bytes, stream))) return rc;
+  if ((rc = svs_conv_c1_run(t.d_logit, B, g.h[0], g.w[0], v.w[11], nullptr, nullptr, nullptr, 0.f, t.dcat[1], 16, 32, 0, stream,
+                            "deconv6 bwd_data", half1))) return rc;
   // decoders 5..1
   long drop_off[5];
   { long o = 0; for (int j = 0; j < 5; ++j) { drop_off[j] = o; o += (long)B * DEC_N[j]; } }
   for (int j = 4; j >= 0; --j) {
     const int lin = 6 - j, lout = 5 - j, l = 6 + j, N = DEC_N[j], C = DEC_C[j];
     const float* x = (j == 0) ? t.c6 : t.cat[lin];
-    rc = svs_bn_bwd_run(t.dcat[lout], 2 * CH[lout], t.raw_d[j], N, g.P[lout], N, (long)g.h[lout] * g.w[lout], v.gamma[l], v.beta[l],
+    const View dyv = cat_half(t.dcat, g, lout, 0);
+    rc = svs_bn_bwd_run(dyv.p, dyv.ld, t.raw_d[j], N, g.P[lout], N, (long)g.h[lout] * g.w[lout], v.gamma[l], v.beta[l],
                         t.mean[l], t.invstd[l], 0.f, drop ? drop + drop_off[j] : nullptr, t.d_raw, G(24 + 4 * j + 2), G(24 + 4 * j + 3),
                         G(24 + 4 * j + 1), t.bnws, t.bnws_bytes, stream);          // + bias gradient (sum of d_raw)
     if (rc) return rc;
@@ -464,18 +485,19 @@ static int train_backward_impl(const ParamView& v, float* grads, const float* mi
   // encoders 6..1
   for (int k = 6; k >= 1; --k) {
     const int l = k - 1, N = CH[k], C = CH[k - 1];
-    const float* dy = (k == 6) ? t.dc6 : t.dcat[k] + CH[k];
-    const long lddy = (k == 6) ? 512 : 2 * CH[k];
+    const View dyv = (k == 6) ? View{t.dc6, 512} : cat_half(t.dcat, g, k, 1);
+    const float* dy = dyv.p; const long lddy = dyv.ld;
     rc = svs_bn_bwd_run(dy, lddy, t.raw_e[k], N, g.P[k], N, (long)g.h[k] * g.w[k], v.gamma[l], v.beta[l], t.mean[l], t.invstd[l],
                         LEAKY, nullptr, t.d_raw, G(4 * l + 2), G(4 * l + 3), G(4 * l + 1), t.bnws, t.bnws_bytes, stream);
     if (rc) return rc;
-    const float* x = (k == 1) ? mix : t.cat[k - 1] + C;
-    const long ldx = (k == 1) ? 1 : 2 * C;
+    const View xi = (k == 1) ? View{const_cast<float*>(mix), 1} : cat_half(t.cat, g, k - 1, 1);
+    const float* x = xi.p; const long ldx = xi.ld;
     if ((rc = svs_enc_block_bwd_weight(t.d_raw, N, B, g.h[k], g.w[k], N, x, ldx, g.h[k - 1], g.w[k - 1], C, G(4 * l), nullptr,
                                        t.scratch, t.scratch_bytes, stream))) return rc;
     if (k >= 2) {
       // gradient of the skip half of cat[k-1]: add to what decoder (7-k)'s bwd_data left there
-      if ((rc = svs_enc_block_bwd_data(t.d_raw, N, B, g.h[k], g.w[k], N, t.wbwd[l], t.dcat[k - 1] + C, 2 * C, g.h[k - 1], g.w[k - 1], C, 1,
+      const View dxs = cat_half(t.dcat, g, k - 1, 1);
+      if ((rc = svs_enc_block_bwd_data(t.d_raw, N, B, g.h[k], g.w[k], N, t.wbwd[l], dxs.p, dxs.ld, g.h[k - 1], g.w[k - 1], C, 1,
                                        t.scratch, t.scratch_bytes, stream))) return rc;
     }
   }

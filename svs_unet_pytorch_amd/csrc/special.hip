@@ -14,7 +14,16 @@ struct C1Args {
   const float* w;                         // [COUT][25]  (torch (COUT,1,5,5) == gather packing with C=1)
   const float* bias; const float* scale; const float* shift; float slope;
   float* y; long ldy; int Ho, Wo; int accumulate;
+  long half;                              // floats between channel COUT/2-1 and COUT/2 of a pixel minus ... see chan_off()
 };
+
+// Address of channel group `sub` (4 channels) of pixel `pix` in a view whose two channel halves may live in
+// different places ("planar" level-1 buffers: the decoder half and the skip half of the 32-channel level-1
+// tensor are two dense 16-channel planes, so that each half is read and written in full 64-byte pieces by
+// its 16-channel producers/consumers).  half == 0: ordinary interleaved view.
+__device__ __forceinline__ long chan_off(long pix, long ld, int sub, int subs_per_half, long half) {
+  return pix * ld + (half ? (sub >= subs_per_half ? half + (sub - subs_per_half) * 4 : sub * 4) : sub * 4);
+}
 
 // One thread = one output pixel, all COUT channels: the 25 input samples are loaded once per pixel (the
 // earlier 4-channels-per-thread mapping re-issued them COUT/4 times and was bound by load issue), the
@@ -72,7 +81,7 @@ __global__ __launch_bounds__(256) void conv_c1_kernel(C1Args p) {
     const int pp = id / G, sub = id - pp * G;
     if (pix0 + pp < P) {
       f32x4 v = *(const f32x4*)(&tile[pp * LD + sub * 4]);
-      float* dst = p.y + (pix0 + pp) * p.ldy + sub * 4;
+      float* dst = p.y + chan_off(pix0 + pp, p.ldy, sub, G / 2, p.half);
       if (p.accumulate) v += *(const f32x4*)dst;
       *(f32x4*)dst = v;
     }
@@ -81,11 +90,11 @@ __global__ __launch_bounds__(256) void conv_c1_kernel(C1Args p) {
 
 int svs_conv_c1_run(const float* x, int B, int H, int W, const float* w, const float* bias, const float* scale,
                     const float* shift, float slope, float* y, long ldy, int N, int accumulate, hipStream_t stream,
-                    const char* who) {
+                    const char* who, long half) {
   SVS_REQUIRE(x && w && y, "%s: null pointer", who);
   SVS_REQUIRE(N == 16 || N == 32, "%s: single-channel conv supports N=16/32, got %d", who, N);
-  SVS_REQUIRE(ldy >= N && ldy % 4 == 0 && svs_aligned16(y), "%s: bad output view", who);
-  C1Args a{x, B, H, W, w, bias, scale, shift, slope, y, ldy, svs_conv_out(H), svs_conv_out(W), accumulate};
+  SVS_REQUIRE(ldy >= (half ? N / 2 : N) && ldy % 4 == 0 && svs_aligned16(y), "%s: bad output view", who);
+  C1Args a{x, B, H, W, w, bias, scale, shift, slope, y, ldy, svs_conv_out(H), svs_conv_out(W), accumulate, half};
   const long total = (long)B * a.Ho * a.Wo;
   const int grid = (int)((total + 255) / 256);
   if (N == 16) hipLaunchKernelGGL(conv_c1_kernel<16>, dim3(grid), dim3(256), 0, stream, a);
@@ -100,6 +109,7 @@ struct To1Args {
   const float* w;                          // torch (CIN,1,5,5) = [c][25]
   const float* bias;                       // device scalar or null
   float* y; int Ho, Wo; int sigmoid;
+  long half;                               // see chan_off()
 };
 
 template <int CIN>
@@ -131,7 +141,7 @@ __global__ __launch_bounds__(256) void deconv_to1_kernel(To1Args p) {
       for (int dw = -1; dw <= 1; ++dw) {
         const int iw = c + dw;
         if (!live || (unsigned)ih >= (unsigned)p.H || (unsigned)iw >= (unsigned)p.W) continue;
-        const f32x4 v = *(const f32x4*)(p.x + ((b * p.H + ih) * p.W + iw) * p.ldx + cg * 4);
+        const f32x4 v = *(const f32x4*)(p.x + chan_off((b * p.H + ih) * p.W + iw, p.ldx, cg, G / 2, p.half));
         const int th = 1 - dh, tw = 1 - dw;
 #pragma unroll
         for (int ph = 0; ph < 2; ++ph) {
@@ -167,12 +177,12 @@ __global__ __launch_bounds__(256) void deconv_to1_kernel(To1Args p) {
 }
 
 int svs_deconv_to1_run(const float* x, long ldx, int B, int H, int W, int C, const float* w, const float* bias,
-                       float* y, int Ho, int Wo, int apply_sigmoid, hipStream_t stream, const char* who) {
+                       float* y, int Ho, int Wo, int apply_sigmoid, hipStream_t stream, const char* who, long half) {
   SVS_REQUIRE(x && w && y, "%s: null pointer", who);
   SVS_REQUIRE(C == 32 || C == 16, "%s: supports C=16/32, got %d", who, C);
   SVS_REQUIRE((Ho == 2 * H || Ho == 2 * H - 1) && (Wo == 2 * W || Wo == 2 * W - 1), "%s: output %dx%d unreachable from %dx%d", who, Ho, Wo, H, W);
-  SVS_REQUIRE(ldx >= C && ldx % 4 == 0 && svs_aligned16(x), "%s: bad input view", who);
-  To1Args a{x, ldx, B, H, W, w, bias, y, Ho, Wo, apply_sigmoid};
+  SVS_REQUIRE(ldx >= (half ? C / 2 : C) && ldx % 4 == 0 && svs_aligned16(x), "%s: bad input view", who);
+  To1Args a{x, ldx, B, H, W, w, bias, y, Ho, Wo, apply_sigmoid, half};
   const long total = (long)B * H * W * (C / 4);
   int grid = (int)((total + 255) / 256);
   if (grid > 8192) grid = 8192;
@@ -188,6 +198,7 @@ struct WgC1Args {
   const float* l; int Hl, Wl;                // (B,Hl,Wl) single channel
   float* slab;                               // [gridDim.x][CS*25]
   long pix_per_block;
+  long half;                                 // see chan_off()
 };
 
 template <int CS>
@@ -209,7 +220,7 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(WgC1Args p) {
     const long tmp = pix / p.Ws;
     const int i = (int)(tmp % p.Hs);
     const long b = tmp / p.Hs;
-    const f32x4 s4 = *(const f32x4*)(p.s + pix * p.lds + cg * 4);
+    const f32x4 s4 = *(const f32x4*)(p.s + chan_off(pix, p.lds, cg, G / 2, p.half));
     const float* img = p.l + b * p.Hl * p.Wl;
 #pragma unroll
     for (int kh = 0; kh < 5; ++kh) {
@@ -278,11 +289,11 @@ size_t svs_wgrad_c1_workspace(int B, int Hs, int Ws, int Cs) {
 }
 
 int svs_wgrad_c1_run(const float* s, long lds, int B, int Hs, int Ws, int Cs, const float* l, int Hl, int Wl,
-                     float* dw, void* ws, size_t ws_bytes, hipStream_t stream, const char* who) {
+                     float* dw, void* ws, size_t ws_bytes, hipStream_t stream, const char* who, long half) {
   SVS_REQUIRE(s && l && dw, "%s: null pointer", who);
   SVS_REQUIRE(Cs == 16 || Cs == 32, "%s: supports Cs=16/32, got %d", who, Cs);
   SVS_REQUIRE(Hs == svs_conv_out(Hl) && Ws == svs_conv_out(Wl), "%s: grid mismatch", who);
-  SVS_REQUIRE(lds >= Cs && lds % 4 == 0 && svs_aligned16(s), "%s: bad view", who);
+  SVS_REQUIRE(lds >= (half ? Cs / 2 : Cs) && lds % 4 == 0 && svs_aligned16(s), "%s: bad view", who);
   const long P = (long)B * Hs * Ws;
   const int nb = wgrad_c1_blocks(P);
   const size_t need = svs_wgrad_c1_workspace(B, Hs, Ws, Cs);
@@ -290,7 +301,7 @@ int svs_wgrad_c1_run(const float* s, long lds, int B, int Hs, int Ws, int Cs, co
     svs_set_error("%s: workspace too small (%zu < %zu)", who, ws_bytes, need);
     return SVS_ERR_WORKSPACE;
   }
-  WgC1Args a{s, lds, B, Hs, Ws, l, Hl, Wl, (float*)ws, (P + nb - 1) / nb};
+  WgC1Args a{s, lds, B, Hs, Ws, l, Hl, Wl, (float*)ws, (P + nb - 1) / nb, half};
   if (Cs == 16) hipLaunchKernelGGL(wgrad_c1_kernel<16>, dim3(nb), dim3(256), 0, stream, a);
   else hipLaunchKernelGGL(wgrad_c1_kernel<32>, dim3(nb), dim3(256), 0, stream, a);
   SVS_CHECK_LAUNCH("wgrad_c1");

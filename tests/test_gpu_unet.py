@@ -60,6 +60,8 @@ def test_eval_forward_golden(golden, report):
         h, w = hw[k]
         if k == 6:
             t = ws_view(model, "eval", "c6", B, H, W, (B, h, w, 512))
+        elif k == 1:        # level 1 is planar: [decoder plane | skip plane], each (B, h, w, 16)
+            t = ws_view(model, "eval", "cat1", B, H, W, (2, B, h, w, 16))[1]
         else:
             t = ws_view(model, "eval", f"cat{k}", B, H, W, (B, h, w, 2 * ch[k]))[..., ch[k]:]
         nchw = t.permute(0, 3, 1, 2).contiguous().cpu()
@@ -73,7 +75,10 @@ def test_eval_forward_golden(golden, report):
     for j in range(1, 6):
         h, w = hw[6 - j]
         n = DEC_IO[j - 1][1]
-        t = ws_view(model, "eval", f"cat{6 - j}", B, H, W, (B, h, w, 2 * n))[..., :n]
+        if j == 5:
+            t = ws_view(model, "eval", "cat1", B, H, W, (2, B, h, w, 16))[0]
+        else:
+            t = ws_view(model, "eval", f"cat{6 - j}", B, H, W, (B, h, w, 2 * n))[..., :n]
         nchw = t.permute(0, 3, 1, 2).contiguous().cpu()
         key = f"tap.deconv{j}.out"
         assert tuple(g[key + ".shape"]) == tuple(nchw.shape)
