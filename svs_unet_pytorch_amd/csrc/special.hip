@@ -112,36 +112,78 @@ struct To1Args {
   long half;                               // see chan_off()
 };
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {           // cross-lane move on the VALU (no LDS round trip)
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
+// One block = a tile of TH x TW input pixels (= 2TH x 2TW outputs) of one image.  The tile plus a one-pixel halo
+// is staged ONCE in LDS (zero-filled outside the image), so every input vector is fetched from HBM once instead
+// of by each of the 9 output quads that use it (PMC: 431 MB per launch before, ~150 MB algorithmic); each lane
+// keeps the 25 x 4 weights of its channel group in registers and combines 9 LDS vectors into its quad's 4
+// partial outputs, which the CIN/4 lanes of a quad then sum with shuffles.
 template <int CIN>
 __global__ __launch_bounds__(256) void deconv_to1_kernel(To1Args p) {
-  constexpr int G = CIN / 4;
-  __shared__ __attribute__((aligned(16))) float wl[25 * CIN];    // [tap][c]
-  for (int i = threadIdx.x; i < 25 * CIN; i += 256) {
-    const int c = i / 25, tap = i - c * 25;
-    wl[tap * CIN + c] = p.w[i];
+  constexpr int G = CIN / 4;                 // lanes per quad
+  constexpr int TH = 8, TW = 32;             // quads per tile
+  constexpr int LP = CIN + 4;                // floats per staged pixel (pad keeps 16-byte alignment, breaks bank stride)
+  __shared__ __attribute__((aligned(16))) float tile_lds[(TH + 2) * (TW + 2) * LP];
+  const int t = threadIdx.x;
+  const int tiles_w = (p.W + TW - 1) / TW, tiles_h = (p.H + TH - 1) / TH;
+  const int ntiles = p.B * tiles_h * tiles_w;
+  // this lane's weights: w[c][tap] for c = 4*cg .. 4*cg+3  (torch (CIN,1,5,5)); loaded once per (persistent) block
+  const int cg = t % G;
+  f32x4 wr[25];
+#pragma unroll
+  for (int tap = 0; tap < 25; ++tap)
+    wr[tap] = (f32x4){p.w[(cg * 4 + 0) * 25 + tap], p.w[(cg * 4 + 1) * 25 + tap], p.w[(cg * 4 + 2) * 25 + tap], p.w[(cg * 4 + 3) * 25 + tap]};
+  const float bias = p.bias ? p.bias[0] : 0.f;
+  constexpr int NPX = (TH + 2) * (TW + 2);
+  constexpr int NST = (NPX * G + 255) / 256;
+  constexpr unsigned OOB = 0x80000000u;                        // >= num_records: the load returns zeros
+  // a block walks a contiguous run of tiles, so the halo rows it shares with the previous tile are still in its XCD's L2
+  const int tile_lo = (int)((long)ntiles * blockIdx.x / gridDim.x), tile_hi = (int)((long)ntiles * (blockIdx.x + 1) / gridDim.x);
+  const unsigned coff = (unsigned)chan_off(0, 0, cg, G / 2, p.half) * 4u;
+  f32x4 stage[NST];
+  auto fetch = [&](int tile) {                                 // global -> registers: one tile plus halo, zero outside the image
+    const int tw0 = (tile % tiles_w) * TW;
+    const int th0 = ((tile / tiles_w) % tiles_h) * TH;
+    const int b = tile / (tiles_w * tiles_h);
+    // buffer loads: out-of-image pixels get the out-of-range offset and read as zero, with no branch around the load
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (long)b * p.H * p.W * p.ldx), 0, OOB, 0x00020000);
+#pragma unroll
+    for (int k = 0; k < NST; ++k) {
+      const int px = t / G + k * (256 / G);
+      const int lw = px % (TW + 2), lh = px / (TW + 2);
+      const int ih = th0 - 1 + lh, iw = tw0 - 1 + lw;
+      const bool ok = px < NPX && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+      const unsigned vo = ok ? (unsigned)((ih * p.W + iw) * (int)p.ldx) * 4u + coff : OOB;
+      stage[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)vo, 0, 0));
+    }
+  };
+  if (tile_lo < tile_hi) fetch(tile_lo);
+  for (int tile = tile_lo; tile < tile_hi; ++tile) {
+  const int tw0 = (tile % tiles_w) * TW;
+  const int th0 = ((tile / tiles_w) % tiles_h) * TH;
+  const long b = tile / (tiles_w * tiles_h);
+  __syncthreads();                                             // the previous tile's readers are done
+#pragma unroll
+  for (int k = 0; k < NST; ++k) {
+    const int px = t / G + k * (256 / G);
+    if (px < NPX) *(f32x4*)(&tile_lds[px * LP + cg * 4]) = stage[k];
   }
   __syncthreads();
-  const float bias = p.bias ? p.bias[0] : 0.f;
-  const long quads = (long)p.B * p.H * p.W;
-  const long total = (quads * G + 255) / 256 * 256;   // keep whole waves alive for the shuffles
-  for (long gid = (long)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (long)gridDim.x * 256) {
-    const int cg = (int)(gid % G);
-    const long qd = gid / G;
-    const bool live = qd < quads;
-    const long qq = live ? qd : 0;
-    const int c = (int)(qq % p.W);
-    const long tmp = qq / p.W;
-    const int a = (int)(tmp % p.H);
-    const long b = tmp / p.H;
-    float o[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+  if (tile + 1 < tile_hi) fetch(tile + 1);                     // in flight while this tile is computed
+  for (int qd = t / G; qd < TH * TW; qd += 256 / G) {          // every lane of a wave runs the same trip count
+    const int lc = qd % TW, la = qd / TW;
+    f32x2 acc[2][2] = {{{0.f, 0.f}, {0.f, 0.f}}, {{0.f, 0.f}, {0.f, 0.f}}};   // channel pairs: one v_pk_fma_f32 per two MACs
 #pragma unroll
-    for (int dh = -1; dh <= 1; ++dh) {
-      const int ih = a + dh;
+    for (int dh = -1; dh <= 1; ++dh)
 #pragma unroll
       for (int dw = -1; dw <= 1; ++dw) {
-        const int iw = c + dw;
-        if (!live || (unsigned)ih >= (unsigned)p.H || (unsigned)iw >= (unsigned)p.W) continue;
-        const f32x4 v = *(const f32x4*)(p.x + chan_off((b * p.H + ih) * p.W + iw, p.ldx, cg, G / 2, p.half));
+        const f32x4 v = *(const f32x4*)(&tile_lds[((la + 1 + dh) * (TW + 2) + lc + 1 + dw) * LP + cg * 4]);
+        const f32x2 vlo = {v[0], v[1]}, vhi = {v[2], v[3]};
         const int th = 1 - dh, tw = 1 - dw;
 #pragma unroll
         for (int ph = 0; ph < 2; ++ph) {
@@ -151,19 +193,25 @@ __global__ __launch_bounds__(256) void deconv_to1_kernel(To1Args p) {
           for (int pw = 0; pw < 2; ++pw) {
             const int kw = pw + 2 * tw;
             if (kw > 4) continue;
-            const f32x4 w4 = *(const f32x4*)(&wl[(kh * 5 + kw) * CIN + cg * 4]);
-            o[ph][pw] += v[0] * w4[0] + v[1] * w4[1] + v[2] * w4[2] + v[3] * w4[3];
+            const f32x4 w4 = wr[kh * 5 + kw];
+            acc[ph][pw] += vlo * (f32x2){w4[0], w4[1]};
+            acc[ph][pw] += vhi * (f32x2){w4[2], w4[3]};
           }
         }
       }
-    }
+    float o[2][2];
 #pragma unroll
     for (int ph = 0; ph < 2; ++ph)
 #pragma unroll
-      for (int pw = 0; pw < 2; ++pw)
-#pragma unroll
-        for (int s = 1; s < G; s <<= 1) o[ph][pw] += __shfl_xor(o[ph][pw], s, 64);
-    if (live && cg < 4) {
+      for (int pw = 0; pw < 2; ++pw) {
+        float r = acc[ph][pw][0] + acc[ph][pw][1];
+        if (G >= 8) r += dpp_f32<0x141>(r);                    // row_half_mirror: lane i <-> 7-i within 8
+        r += dpp_f32<0xB1>(r);                                 // quad_perm [1,0,3,2]
+        r += dpp_f32<0x4E>(r);                                 // quad_perm [2,3,0,1]
+        o[ph][pw] = r;
+      }
+    const int a = th0 + la, c = tw0 + lc;
+    if (cg < 4 && a < p.H && c < p.W) {
       const int ph = cg >> 1, pw = cg & 1;
       float v = (cg == 0) ? o[0][0] : (cg == 1) ? o[0][1] : (cg == 2) ? o[1][0] : o[1][1];
       const int oh = 2 * a + ph, ow = 2 * c + pw;
@@ -174,6 +222,7 @@ __global__ __launch_bounds__(256) void deconv_to1_kernel(To1Args p) {
       }
     }
   }
+  }
 }
 
 int svs_deconv_to1_run(const float* x, long ldx, int B, int H, int W, int C, const float* w, const float* bias,
@@ -183,9 +232,10 @@ int svs_deconv_to1_run(const float* x, long ldx, int B, int H, int W, int C, con
   SVS_REQUIRE((Ho == 2 * H || Ho == 2 * H - 1) && (Wo == 2 * W || Wo == 2 * W - 1), "%s: output %dx%d unreachable from %dx%d", who, Ho, Wo, H, W);
   SVS_REQUIRE(ldx >= (half ? C / 2 : C) && ldx % 4 == 0 && svs_aligned16(x), "%s: bad input view", who);
   To1Args a{x, ldx, B, H, W, w, bias, y, Ho, Wo, apply_sigmoid, half};
-  const long total = (long)B * H * W * (C / 4);
-  int grid = (int)((total + 255) / 256);
-  if (grid > 8192) grid = 8192;
+  const long grid_l = (long)B * ((H + 7) / 8) * ((W + 31) / 32);
+  SVS_REQUIRE(grid_l < (1L << 31), "%s: too many tiles", who);
+  SVS_REQUIRE(((long)H * W * ldx + half) * 4 < (1L << 31), "%s: one image of the input view must span < 2 GiB", who);
+  const int grid = (int)(grid_l < 512 ? grid_l : 512);     // persistent: 2 blocks per CU, weights loaded once per block
   if (C == 32) hipLaunchKernelGGL(deconv_to1_kernel<32>, dim3(grid), dim3(256), 0, stream, a);
   else hipLaunchKernelGGL(deconv_to1_kernel<16>, dim3(grid), dim3(256), 0, stream, a);
   SVS_CHECK_LAUNCH("deconv_to1");
