@@ -385,6 +385,130 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvGemmArgs p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// LDS-window variant of the PARITY mode for the shallow layers (few channels, many pixels: deconv5 forward,
+// conv2 backward-data).  A block owns TH x TW anchor pixels of one image (= a 2TH x 2TW output patch, all four
+// output parities), stages that window plus a one-pixel halo ONCE in LDS (zero-filled outside the image) and
+// every tap of every parity class then reads its MFMA A-fragment from LDS at base + compile-time offset: no
+// per-tap address arithmetic, no validity masks, no re-fetch of the input through L1/L2 (the direct kernel
+// fetched 5-6x the algorithmic bytes on these layers, profiles/r01_pmc_traffic.json).  Each wave owns two anchor
+// rows (two 16-pixel row tiles); the weight fragments come straight from global memory (they are shared by
+// every block, so they live in L2/L1) and are prefetched one tap ahead.
+// ------------------------------------------------------------------------------------------------
+template <int C, int TN>
+__global__ __launch_bounds__(256) void parity_window_kernel(ConvGemmArgs p) {
+  constexpr int TH = 8, TW = 16, TM = 2;
+  constexpr int LP = C + 4;                    // floats per staged pixel: 16-byte aligned, conflict-free b128 reads
+  constexpr int WW = TW + 2, NPX = (TH + 2) * WW;
+  constexpr int CQ = C / 4, CC = C / 16;
+  constexpr int NST = (NPX * CQ + 255) / 256;
+  constexpr unsigned OOB = 0x80000000u;
+  __shared__ __attribute__((aligned(16))) float win[NPX * LP];
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int lrow = lane & 15, q = lane >> 4;
+  const int tiles_w = (p.W + TW - 1) / TW, tiles_h = (p.H + TH - 1) / TH;
+  const int tile = blockIdx.x;
+  const int tw0 = (tile % tiles_w) * TW;
+  const int th0 = ((tile / tiles_w) % tiles_h) * TH;
+  const long b = tile / (tiles_w * tiles_h);
+  {
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + b * p.H * p.W * p.ldx), 0, OOB, 0x00020000);
+    f32x4 stage[NST];
+#pragma unroll
+    for (int k = 0; k < NST; ++k) {
+      const int e = t + k * 256;
+      const int cq = e % CQ, px = e / CQ;
+      const int lw = px % WW, lh = px / WW;
+      const int ih = th0 - 1 + lh, iw = tw0 - 1 + lw;
+      const bool ok = px < NPX && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+      const unsigned vo = ok ? (unsigned)(((ih * p.W + iw) * (int)p.ldx + cq * 4) * 4) : OOB;
+      stage[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)vo, 0, 0));
+    }
+#pragma unroll
+    for (int k = 0; k < NST; ++k) {
+      const int e = t + k * 256;
+      const int cq = e % CQ, px = e / CQ;
+      if (px < NPX) *(f32x4*)(&win[px * LP + cq * 4]) = stage[k];
+    }
+  }
+  __syncthreads();
+  // A-fragment base of row tile i: anchor (2*wave + i, lrow), channel quarter q, at window coordinate (+1, +1)
+  const float* abase = &win[((2 * wave + 1) * WW + lrow + 1) * LP + q * 4];
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, OOB, 0x00020000);
+#pragma unroll
+  for (int par = 0; par < 4; ++par) {
+    constexpr int POFF[4] = {0, 9, 15, 21};
+    const int ph = par >> 1, pw = par & 1;
+    const int nth = 3 - ph, ntw = 3 - pw, ntaps = nth * ntw;
+    const int Kw = ntaps * C;
+    unsigned b_voff[TN];
+    // class weights start at POFF*N*C floats; row n of the class holds Kw floats
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b_voff[j] = (unsigned)((POFF[par] * p.N * C + (j * 16 + lrow) * Kw + q * 4) * 4);
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 fb[2][CC][TN];
+    auto load_b = [&](int tap, f32x4 (&dst)[CC][TN]) {
+#pragma unroll
+      for (int cc = 0; cc < CC; ++cc)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          dst[cc][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (int)b_voff[j], (tap * C + cc * 16) * 4, 0));
+    };
+    load_b(0, fb[0]);
+#pragma unroll
+    for (int tap = 0; tap < ntaps; ++tap) {
+      if (tap + 1 < ntaps) load_b(tap + 1, fb[(tap + 1) & 1]);
+      const int th = tap / ntw, tw = tap % ntw;
+      const int aoff = ((1 - th) * WW + (1 - tw)) * LP;           // compile-time after unrolling
+#pragma unroll
+      for (int cc = 0; cc < CC; ++cc) {
+        f32x4 fa[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[i] = *(const f32x4*)(abase + aoff + i * WW * LP + cc * 16);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][k], fb[tap & 1][cc][j][k], acc[i][j], 0, 0, 0);
+      }
+    }
+    // rows q*4 + r of row tile i = anchor (th0 + 2*wave + i, tw0 + q*4 + r); column lrow (+16j) = output channel
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int a = th0 + 2 * wave + i;
+      const int oh = 2 * a + ph;
+      if (a >= p.H || oh >= p.Ho) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = tw0 + q * 4 + r;
+        const int ow = 2 * c + pw;
+        if (c >= p.W || ow >= p.Wo) continue;
+        const long opix = (b * p.Ho + oh) * p.Wo + ow;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int n = j * 16 + lrow;
+          float v = acc[i][j][r];
+          if (p.bias) v += p.bias[n];
+          if (p.scale) {
+            v = v * p.scale[n] + p.shift[n];
+            v = v > 0.f ? v : v * p.slope;
+          }
+          float* dst = p.y + opix * p.ldy + n;
+          if (p.accumulate) v += *dst;
+          *dst = v;
+        }
+      }
+    }
+  }
+}
+
 // out[pix][n] = epi(sum_z slab[z][pix][n] + bias[n])
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __restrict__ slab, int ksplit, long P, int N,
                                                               const float* __restrict__ bias,
@@ -480,6 +604,18 @@ static int check_gemm_args(const char* who, const float* x, long ldx, int B, int
   return SVS_OK;
 }
 
+// LDS-window kernel for the shallow parity layers (N = 16, C = 32 / 64, large images)
+static int use_parity_window(int mode, int B, int H, int W, int C, int N, long ldx) {
+  const bool eligible = mode == MODE_PARITY && N == 16 && (C == 32 || C == 64) && ((long)H * W * ldx) * 4 < (1L << 31);
+  const bool fills_gpu = H >= 8 && W >= 16 && (long)B * ((H + 7) / 8) * ((W + 15) / 16) >= 1024;
+  int window = eligible && fills_gpu;
+  if (const char* e = getenv("SVS_CONV_WINDOW")) {     // sweeps and tests: 0 = never, 2 = whenever the shape is eligible
+    const int f = atoi(e);
+    window = (f == 0) ? 0 : (f == 2) ? eligible : window;
+  }
+  return window;
+}
+
 // Shared by enc fwd / dec bwd_data (GATHER) and dec fwd / enc bwd_data (PARITY).
 int svs_conv_gemm_run(int mode, const float* x, long ldx, int B, int H, int W, int C, const float* wp,
                       const float* bias, const float* scale, const float* shift, float slope, float* y, long ldy,
@@ -507,13 +643,16 @@ int svs_conv_gemm_run(int mode, const float* x, long ldx, int B, int H, int W, i
   a.x = x; a.ldx = ldx; a.B = B; a.H = H; a.W = W; a.C = C; a.wp = wp;
   a.bias = bias; a.scale = scale; a.shift = shift; a.slope = slope;
   a.y = y; a.ldy = ldy; a.Ho = Ho; a.Wo = Wo; a.N = N; a.accumulate = accumulate;
-  a.ksplit = pl.ksplit; a.slab = nullptr;
+  a.slab = nullptr;
   // With few output channels the im2col operand dominates the traffic; consuming all taps of a 16-channel
   // chunk before the next chunk keeps a block's re-read window in cache (same-device A/B: 5% faster for the
   // N<=32 layers, 1-2% slower for the deep ones, hence the switch).
   a.tap_inner = N <= 32;
   if (const char* e = getenv("SVS_CONV_KORDER")) a.tap_inner = atoi(e) != 0;     // sweeps only
   const long P = (long)B * Ho * Wo;
+  const int window = use_parity_window(mode, B, H, W, C, N, ldx);
+  if (window) pl.ksplit = 1;
+  a.ksplit = pl.ksplit;
   if (pl.ksplit > 1) {
     const size_t need = (size_t)pl.ksplit * P * N * sizeof(float);
     if (!ws || ws_bytes < need || !svs_aligned16(ws)) {
@@ -530,6 +669,14 @@ int svs_conv_gemm_run(int mode, const float* x, long ldx, int B, int H, int W, i
     else if (N == 32 && mode == MODE_PARITY && C >= 128) direct = 1;
   }
   if (const char* e = getenv("SVS_CONV_DIRECT")) { const int f = atoi(e); if (f == 0 || (N <= 32 && Mmax >= 16384)) direct = f; }  // sweeps
+  if (window) {
+    a.ksplit = 1; a.slab = nullptr;
+    dim3 grid((unsigned)((long)B * ((H + 7) / 8) * ((W + 15) / 16)));
+    if (C == 32) hipLaunchKernelGGL((parity_window_kernel<32, 1>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((parity_window_kernel<64, 1>), grid, dim3(256), 0, stream, a);
+    SVS_CHECK_LAUNCH("parity_window");
+    return SVS_OK;
+  }
   if (direct && (N == 16 || N == 32)) {
     a.ksplit = 1; a.slab = nullptr;
     const int rows = (direct == 2 ? 8 : 4) * 64;      // 4 independent waves per block, TM*16 output rows each
@@ -582,6 +729,7 @@ int svs_conv_gemm_describe(int mode, int B, int H, int W, int C, int Ho, int Wo,
     if (N == 16) direct = 1;
     else if (N == 32 && mode == MODE_PARITY && C >= 128) direct = 1;
   }
+  if (use_parity_window(mode, B, H, W, C, N, ldx)) { snprintf(buf, n, "parity_window_kernel<%d, 1>", C); return 1; }
   if (direct) { snprintf(buf, n, "conv_direct_kernel<%d, 4, %d>", mode, N / 16); return 1; }
   static const int wm[10] = {2, 2, 4, 4, 1, 2, 2, 4, 4, 4}, wn[10] = {2, 2, 1, 1, 4, 2, 2, 1, 1, 1};
   const ConvPlan pl = plan_conv(mode, Mmax, N, nkt_min);

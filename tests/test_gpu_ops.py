@@ -2,6 +2,8 @@
 computation of the same op (torch.nn.functional on NCHW tensors), on seeded inputs.  Tolerances are
 relative to the output's magnitude; fp32 MFMA is an exact fmaf chain, so the only error is
 summation order (~1e-6 relative)."""
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -177,6 +179,50 @@ def test_dec_block_fwd(B, H, W, C, N, Ho, Wo, report):
     _lib.check(L().svs_dec_block_fwd(xd.data_ptr(), C, B, H, W, C, wp.data_ptr(), None, scd.data_ptr(), shd.data_ptr(), 0.0,
                                      y2.data_ptr(), N, Ho, Wo, N, 0, ws.data_ptr(), ws.numel(), S()))
     assert report(f"dec_fwd epi B{B} {H}x{W}->{Ho}x{Wo} C{C} N{N}", relerr(nchw(y2), want2), 2e-5)
+
+
+WINDOW_CASES = [
+    # B, H, W, C, Ho, Wo  (N = 16: the LDS-window parity kernel, forced on shapes that would not fill the GPU)
+    (2, 64, 16, 64, 128, 32),
+    (1, 9, 18, 64, 17, 35),         # ragged tiles, odd output
+    (2, 16, 32, 32, 32, 64),
+    (1, 13, 17, 32, 26, 33),
+    (1, 3, 5, 64, 6, 10),           # smaller than one tile
+]
+
+
+@pytest.mark.parametrize("B,H,W,C,Ho,Wo", WINDOW_CASES)
+def test_parity_window_kernel(B, H, W, C, Ho, Wo, report, monkeypatch):
+    monkeypatch.setenv("SVS_CONV_WINDOW", "2")
+    N = 16
+    buf = ctypes.create_string_buffer(128)
+    L().svs_describe_plan(1, B, H, W, C, Ho, Wo, N, buf, 128)
+    assert buf.value.decode().startswith("parity_window_kernel"), buf.value
+    x = rnd((B, C, H, W), 35)
+    w = rnd((C, N, 5, 5), 36, -0.1, 0.1)
+    b = rnd((N,), 37)
+    op = (Ho - (2 * H - 1), Wo - (2 * W - 1))
+    want = F.conv_transpose2d(x.double(), w.double(), b.double(), stride=2, padding=2, output_padding=op)
+    xd = torch.full((B, H, W, C + 8), 7.0, device=DEV)          # strided input view: the pad columns must never be read
+    xd[..., :C] = nhwc(x).to(DEV)
+    wp, bd = pack_parity(w), b.to(DEV)
+    y = torch.full((B, Ho, Wo, 2 * N), -3.0, device=DEV)
+    ws = ws_tensor(64)
+    _lib.check(L().svs_dec_block_fwd(xd.data_ptr(), C + 8, B, H, W, C, wp.data_ptr(), bd.data_ptr(), None, None, 0.0,
+                                     y.data_ptr(), 2 * N, Ho, Wo, N, 0, ws.data_ptr(), ws.numel(), S()))
+    torch.cuda.synchronize()
+    assert torch.all(y[..., N:] == -3.0)
+    assert report(f"window dec_fwd B{B} {H}x{W}->{Ho}x{Wo} C{C}", relerr(nchw(y[..., :N]), want), 2e-5)
+    # accumulate + folded-BN epilogue, and bit-identical to the direct kernel's arithmetic order is NOT required: compare to fp64
+    sc, sh = rnd((N,), 38, 0.5, 1.5), rnd((N,), 39)
+    base = rnd((B, Ho, Wo, N), 44)
+    want2 = F.relu(F.conv_transpose2d(x.double(), w.double(), None, stride=2, padding=2, output_padding=op)
+                   * sc.double()[None, :, None, None] + sh.double()[None, :, None, None]) + nchw(base).double()
+    y2 = base.clone().to(DEV)
+    scd, shd = sc.to(DEV), sh.to(DEV)
+    _lib.check(L().svs_dec_block_fwd(xd.data_ptr(), C + 8, B, H, W, C, wp.data_ptr(), None, scd.data_ptr(), shd.data_ptr(), 0.0,
+                                     y2.data_ptr(), N, Ho, Wo, N, 1, ws.data_ptr(), ws.numel(), S()))
+    assert report(f"window dec_fwd epi+acc B{B} {H}x{W}->{Ho}x{Wo} C{C}", relerr(nchw(y2), want2), 2e-5)
 
 
 def test_out_block_fwd(report):
