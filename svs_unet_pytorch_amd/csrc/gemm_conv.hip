@@ -20,6 +20,7 @@
 // Bound: MFMA (fp32 157.3 TFLOP/s peak); algorithmic FLOPs = 2*M*N*K.
 #include <stdlib.h>
 
+#include <type_traits>
 #include "common.h"
 
 enum { MODE_GATHER = 0, MODE_PARITY = 1 };
@@ -385,6 +386,14 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvGemmArgs p) {
   }
 }
 
+template <int N_, int I_ = 0, class F>
+__device__ __forceinline__ void svs_static_for(F&& f) {        // f(integral_constant<int, I>) for I = 0 .. N-1, unrolled
+  if constexpr (I_ < N_) {
+    f(std::integral_constant<int, I_>{});
+    svs_static_for<N_, I_ + 1>(f);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // LDS-window variant of the PARITY mode for the shallow layers (few channels, many pixels: deconv5 forward,
 // conv2 backward-data).  A block owns TH x TW anchor pixels of one image (= a 2TH x 2TW output patch, all four
@@ -395,14 +404,15 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvGemmArgs p) {
 // rows (two 16-pixel row tiles); the weight fragments come straight from global memory (they are shared by
 // every block, so they live in L2/L1) and are prefetched one tap ahead.
 // ------------------------------------------------------------------------------------------------
-template <int C, int TN>
+template <int C, int CW, int TN>              // C input channels, CW of them per staging phase; N = 16 * TN
 __global__ __launch_bounds__(256) void parity_window_kernel(ConvGemmArgs p) {
   constexpr int TH = 8, TW = 16, TM = 2;
-  constexpr int LP = C + 4;                    // floats per staged pixel: 16-byte aligned, conflict-free b128 reads
+  constexpr int LP = CW + 4;                   // floats per staged pixel: 16-byte aligned, conflict-free b128 reads
   constexpr int WW = TW + 2, NPX = (TH + 2) * WW;
-  constexpr int CQ = C / 4, CC = C / 16;
+  constexpr int CQ = CW / 4, CC = CW / 16;
   constexpr int NST = (NPX * CQ + 255) / 256;
   constexpr unsigned OOB = 0x80000000u;
+  constexpr int POFF[4] = {0, 9, 15, 21};
   __shared__ __attribute__((aligned(16))) float win[NPX * LP];
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
@@ -412,8 +422,11 @@ __global__ __launch_bounds__(256) void parity_window_kernel(ConvGemmArgs p) {
   const int tw0 = (tile % tiles_w) * TW;
   const int th0 = ((tile / tiles_w) % tiles_h) * TH;
   const long b = tile / (tiles_w * tiles_h);
-  {
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + b * p.H * p.W * p.ldx), 0, OOB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + b * p.H * p.W * p.ldx), 0, OOB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, OOB, 0x00020000);
+  // A-fragment base of row tile i: anchor (2*wave + i, lrow), channel quarter q, at window coordinate (+1, +1)
+  const float* abase = &win[((2 * wave + 1) * WW + lrow + 1) * LP + q * 4];
+  auto stage_window = [&](int phase) {                             // global -> registers -> LDS, zero outside the image
     f32x4 stage[NST];
 #pragma unroll
     for (int k = 0; k < NST; ++k) {
@@ -422,64 +435,62 @@ __global__ __launch_bounds__(256) void parity_window_kernel(ConvGemmArgs p) {
       const int lw = px % WW, lh = px / WW;
       const int ih = th0 - 1 + lh, iw = tw0 - 1 + lw;
       const bool ok = px < NPX && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-      const unsigned vo = ok ? (unsigned)(((ih * p.W + iw) * (int)p.ldx + cq * 4) * 4) : OOB;
+      const unsigned vo = ok ? (unsigned)(((ih * p.W + iw) * (int)p.ldx + phase * CW + cq * 4) * 4) : OOB;
       stage[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)vo, 0, 0));
     }
+    if (phase) __syncthreads();                                    // the previous phase's readers are done
 #pragma unroll
     for (int k = 0; k < NST; ++k) {
       const int e = t + k * 256;
       const int cq = e % CQ, px = e / CQ;
       if (px < NPX) *(f32x4*)(&win[px * LP + cq * 4]) = stage[k];
     }
-  }
-  __syncthreads();
-  // A-fragment base of row tile i: anchor (2*wave + i, lrow), channel quarter q, at window coordinate (+1, +1)
-  const float* abase = &win[((2 * wave + 1) * WW + lrow + 1) * LP + q * 4];
-  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, OOB, 0x00020000);
+    __syncthreads();
+  };
+  // The 25 taps in class order (9 + 6 + 6 + 4).  Step s = (class par, tap within class); the weight fragments of
+  // step s + 1 (possibly the next class's first tap) are requested before step s's MFMAs, and a scheduling barrier
+  // after every step keeps the compiler from hoisting later steps' loads on top (which costs a third of the occupancy).
+  unsigned b_voff[TN];
 #pragma unroll
-  for (int par = 0; par < 4; ++par) {
-    constexpr int POFF[4] = {0, 9, 15, 21};
-    const int ph = par >> 1, pw = par & 1;
-    const int nth = 3 - ph, ntw = 3 - pw, ntaps = nth * ntw;
-    const int Kw = ntaps * C;
-    unsigned b_voff[TN];
-    // class weights start at POFF*N*C floats; row n of the class holds Kw floats
+  for (int j = 0; j < TN; ++j) b_voff[j] = (unsigned)((j * 16 + lrow) * C * 4);   // one tap's row pitch; x ntaps of the class below
+  f32x4 fb[2][CC][TN];
+  auto load_b = [&](auto sc, int phase) {
+    constexpr int s_ = decltype(sc)::value;
+    constexpr int par = s_ < 9 ? 0 : s_ < 15 ? 1 : s_ < 21 ? 2 : 3;
+    constexpr int tap = s_ - POFF[par];
+    constexpr int ntaps = (3 - (par >> 1)) * (3 - (par & 1));
+    // class weights start at POFF*N*C floats; row n of the class holds ntaps*C floats
 #pragma unroll
-    for (int j = 0; j < TN; ++j) b_voff[j] = (unsigned)((POFF[par] * p.N * C + (j * 16 + lrow) * Kw + q * 4) * 4);
-    f32x4 acc[TM][TN];
+    for (int cc = 0; cc < CC; ++cc)
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+      for (int j = 0; j < TN; ++j)
+        fb[s_ & 1][cc][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+            rw, (int)(b_voff[j] * ntaps + q * 16 + phase * (CW * 4)), (POFF[par] * (TN * 16) * C + tap * C + cc * 16) * 4, 0));
+  };
+  auto step = [&](auto sc, f32x4 (&acc)[TM][TN]) {
+    constexpr int s_ = decltype(sc)::value;
+    constexpr int par = s_ < 9 ? 0 : s_ < 15 ? 1 : s_ < 21 ? 2 : 3;
+    constexpr int tap = s_ - POFF[par];
+    constexpr int ntw = 3 - (par & 1);
+    constexpr int th = tap / ntw, tw = tap % ntw;
+    constexpr int aoff = ((1 - th) * WW + (1 - tw)) * LP;
 #pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    f32x4 fb[2][CC][TN];
-    auto load_b = [&](int tap, f32x4 (&dst)[CC][TN]) {
+    for (int cc = 0; cc < CC; ++cc) {
+      f32x4 fa[TM];
 #pragma unroll
-      for (int cc = 0; cc < CC; ++cc)
+      for (int i = 0; i < TM; ++i) fa[i] = *(const f32x4*)(abase + aoff + i * WW * LP + cc * 16);
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          dst[cc][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (int)b_voff[j], (tap * C + cc * 16) * 4, 0));
-    };
-    load_b(0, fb[0]);
+      for (int k = 0; k < 4; ++k)
 #pragma unroll
-    for (int tap = 0; tap < ntaps; ++tap) {
-      if (tap + 1 < ntaps) load_b(tap + 1, fb[(tap + 1) & 1]);
-      const int th = tap / ntw, tw = tap % ntw;
-      const int aoff = ((1 - th) * WW + (1 - tw)) * LP;           // compile-time after unrolling
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int cc = 0; cc < CC; ++cc) {
-        f32x4 fa[TM];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) fa[i] = *(const f32x4*)(abase + aoff + i * WW * LP + cc * 16);
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][k], fb[tap & 1][cc][j][k], acc[i][j], 0, 0, 0);
-      }
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][k], fb[s_ & 1][cc][j][k], acc[i][j], 0, 0, 0);
     }
-    // rows q*4 + r of row tile i = anchor (th0 + 2*wave + i, tw0 + q*4 + r); column lrow (+16j) = output channel
+  };
+  // rows q*4 + r of row tile i = anchor (th0 + 2*wave + i, tw0 + q*4 + r); column lrow (+16j) = output channel
+  auto store_class = [&](int par, const f32x4 (&acc)[TM][TN]) {
+    const int ph = par >> 1, pw = par & 1;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int a = th0 + 2 * wave + i;
@@ -506,6 +517,46 @@ __global__ __launch_bounds__(256) void parity_window_kernel(ConvGemmArgs p) {
         }
       }
     }
+  };
+  auto zero = [&](f32x4 (&acc)[TM][TN]) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  };
+  if constexpr (C == CW) {                     // one phase: one class at a time, 2*TN accumulators live
+    stage_window(0);
+    f32x4 acc[TM][TN];
+    load_b(std::integral_constant<int, 0>{}, 0);
+    svs_static_for<25>([&](auto sc) {
+      constexpr int s_ = decltype(sc)::value;
+      constexpr int par = s_ < 9 ? 0 : s_ < 15 ? 1 : s_ < 21 ? 2 : 3;
+      if constexpr (s_ == POFF[par]) zero(acc);
+      if constexpr (s_ + 1 < 25) load_b(std::integral_constant<int, (s_ + 1 < 25 ? s_ + 1 : 0)>{}, 0);
+      if constexpr (CC >= 4) __builtin_amdgcn_sched_barrier(0);
+      step(sc, acc);
+      if constexpr (s_ == 24 || s_ + 1 == POFF[par < 3 ? par + 1 : 3]) store_class(par, acc);
+      if constexpr (CC >= 4) __builtin_amdgcn_sched_barrier(0);     // (32-channel steps are too short to fence)
+    });
+  } else {                                     // several phases share the window buffer: all four classes stay live
+    f32x4 acc[4][TM][TN];
+#pragma unroll
+    for (int par = 0; par < 4; ++par) zero(acc[par]);
+#pragma unroll 1
+    for (int phase = 0; phase < C / CW; ++phase) {
+      stage_window(phase);
+      load_b(std::integral_constant<int, 0>{}, phase);
+      svs_static_for<25>([&](auto sc) {
+        constexpr int s_ = decltype(sc)::value;
+        constexpr int par = s_ < 9 ? 0 : s_ < 15 ? 1 : s_ < 21 ? 2 : 3;
+        if constexpr (s_ + 1 < 25) load_b(std::integral_constant<int, (s_ + 1 < 25 ? s_ + 1 : 0)>{}, phase);
+        __builtin_amdgcn_sched_barrier(0);
+        step(sc, acc[par]);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    }
+#pragma unroll
+    for (int par = 0; par < 4; ++par) store_class(par, acc[par]);
   }
 }
 
@@ -604,10 +655,11 @@ static int check_gemm_args(const char* who, const float* x, long ldx, int B, int
   return SVS_OK;
 }
 
-// LDS-window kernel for the shallow parity layers (N = 16, C = 32 / 64, large images)
+// LDS-window kernel for the shallow parity layers (N = 16 / 32, C = 32 / 64 / 128, large images)
 static int use_parity_window(int mode, int B, int H, int W, int C, int N, long ldx) {
-  const bool eligible = mode == MODE_PARITY && N == 16 && (C == 32 || C == 64) && ((long)H * W * ldx) * 4 < (1L << 31);
-  const bool fills_gpu = H >= 8 && W >= 16 && (long)B * ((H + 7) / 8) * ((W + 15) / 16) >= 1024;
+  const bool eligible = mode == MODE_PARITY && (N == 16 || N == 32) && (C == 32 || C == 64 || C == 128) &&
+                        ((long)H * W * ldx) * 4 < (1L << 31);
+  const bool fills_gpu = H >= 8 && W >= 16 && (long)B * ((H + 7) / 8) * ((W + 15) / 16) >= 512;
   int window = eligible && fills_gpu;
   if (const char* e = getenv("SVS_CONV_WINDOW")) {     // sweeps and tests: 0 = never, 2 = whenever the shape is eligible
     const int f = atoi(e);
@@ -672,8 +724,13 @@ int svs_conv_gemm_run(int mode, const float* x, long ldx, int B, int H, int W, i
   if (window) {
     a.ksplit = 1; a.slab = nullptr;
     dim3 grid((unsigned)((long)B * ((H + 7) / 8) * ((W + 15) / 16)));
-    if (C == 32) hipLaunchKernelGGL((parity_window_kernel<32, 1>), grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((parity_window_kernel<64, 1>), grid, dim3(256), 0, stream, a);
+#define SVS_LAUNCH_WINDOW(C_, CW_, TN_) hipLaunchKernelGGL((parity_window_kernel<C_, CW_, TN_>), grid, dim3(256), 0, stream, a)
+    if (N == 16) {
+      if (C == 32) SVS_LAUNCH_WINDOW(32, 32, 1); else if (C == 64) SVS_LAUNCH_WINDOW(64, 64, 1); else SVS_LAUNCH_WINDOW(128, 64, 1);
+    } else {
+      if (C == 32) SVS_LAUNCH_WINDOW(32, 32, 2); else if (C == 64) SVS_LAUNCH_WINDOW(64, 64, 2); else SVS_LAUNCH_WINDOW(128, 64, 2);
+    }
+#undef SVS_LAUNCH_WINDOW
     SVS_CHECK_LAUNCH("parity_window");
     return SVS_OK;
   }
@@ -729,7 +786,7 @@ int svs_conv_gemm_describe(int mode, int B, int H, int W, int C, int Ho, int Wo,
     if (N == 16) direct = 1;
     else if (N == 32 && mode == MODE_PARITY && C >= 128) direct = 1;
   }
-  if (use_parity_window(mode, B, H, W, C, N, ldx)) { snprintf(buf, n, "parity_window_kernel<%d, 1>", C); return 1; }
+  if (use_parity_window(mode, B, H, W, C, N, ldx)) { snprintf(buf, n, "parity_window_kernel<%d, %d, %d>", C, C == 32 ? 32 : 64, N / 16); return 1; }
   if (direct) { snprintf(buf, n, "conv_direct_kernel<%d, 4, %d>", mode, N / 16); return 1; }
   static const int wm[10] = {2, 2, 4, 4, 1, 2, 2, 4, 4, 4}, wn[10] = {2, 2, 1, 1, 4, 2, 2, 1, 1, 1};
   const ConvPlan pl = plan_conv(mode, Mmax, N, nkt_min);

@@ -182,19 +182,22 @@ def test_dec_block_fwd(B, H, W, C, N, Ho, Wo, report):
 
 
 WINDOW_CASES = [
-    # B, H, W, C, Ho, Wo  (N = 16: the LDS-window parity kernel, forced on shapes that would not fill the GPU)
-    (2, 64, 16, 64, 128, 32),
-    (1, 9, 18, 64, 17, 35),         # ragged tiles, odd output
-    (2, 16, 32, 32, 32, 64),
-    (1, 13, 17, 32, 26, 33),
-    (1, 3, 5, 64, 6, 10),           # smaller than one tile
+    # B, H, W, C, N, Ho, Wo  (the LDS-window parity kernel, forced on shapes that would not fill the GPU)
+    (2, 64, 16, 64, 16, 128, 32),
+    (1, 9, 18, 64, 16, 17, 35),         # ragged tiles, odd output
+    (2, 16, 32, 32, 16, 32, 64),
+    (1, 13, 17, 32, 16, 26, 33),
+    (1, 3, 5, 64, 16, 6, 10),           # smaller than one tile
+    (2, 16, 16, 128, 32, 32, 32),       # two staging phases, two column tiles (deconv4 forward)
+    (1, 9, 18, 128, 16, 18, 35),
+    (2, 16, 16, 64, 32, 31, 32),        # conv3 backward-data
+    (1, 11, 20, 32, 32, 21, 40),
 ]
 
 
-@pytest.mark.parametrize("B,H,W,C,Ho,Wo", WINDOW_CASES)
-def test_parity_window_kernel(B, H, W, C, Ho, Wo, report, monkeypatch):
+@pytest.mark.parametrize("B,H,W,C,N,Ho,Wo", WINDOW_CASES)
+def test_parity_window_kernel(B, H, W, C, N, Ho, Wo, report, monkeypatch):
     monkeypatch.setenv("SVS_CONV_WINDOW", "2")
-    N = 16
     buf = ctypes.create_string_buffer(128)
     L().svs_describe_plan(1, B, H, W, C, Ho, Wo, N, buf, 128)
     assert buf.value.decode().startswith("parity_window_kernel"), buf.value
@@ -212,7 +215,7 @@ def test_parity_window_kernel(B, H, W, C, Ho, Wo, report, monkeypatch):
                                      y.data_ptr(), 2 * N, Ho, Wo, N, 0, ws.data_ptr(), ws.numel(), S()))
     torch.cuda.synchronize()
     assert torch.all(y[..., N:] == -3.0)
-    assert report(f"window dec_fwd B{B} {H}x{W}->{Ho}x{Wo} C{C}", relerr(nchw(y[..., :N]), want), 2e-5)
+    assert report(f"window dec_fwd B{B} {H}x{W}->{Ho}x{Wo} C{C} N{N}", relerr(nchw(y[..., :N]), want), 2e-5)
     # accumulate + folded-BN epilogue, and bit-identical to the direct kernel's arithmetic order is NOT required: compare to fp64
     sc, sh = rnd((N,), 38, 0.5, 1.5), rnd((N,), 39)
     base = rnd((B, Ho, Wo, N), 44)
@@ -222,7 +225,7 @@ def test_parity_window_kernel(B, H, W, C, Ho, Wo, report, monkeypatch):
     scd, shd = sc.to(DEV), sh.to(DEV)
     _lib.check(L().svs_dec_block_fwd(xd.data_ptr(), C + 8, B, H, W, C, wp.data_ptr(), None, scd.data_ptr(), shd.data_ptr(), 0.0,
                                      y2.data_ptr(), N, Ho, Wo, N, 1, ws.data_ptr(), ws.numel(), S()))
-    assert report(f"window dec_fwd epi+acc B{B} {H}x{W}->{Ho}x{Wo} C{C}", relerr(nchw(y2), want2), 2e-5)
+    assert report(f"window dec_fwd epi+acc B{B} {H}x{W}->{Ho}x{Wo} C{C} N{N}", relerr(nchw(y2), want2), 2e-5)
 
 
 def test_out_block_fwd(report):
