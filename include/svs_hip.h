@@ -47,6 +47,9 @@ int svs_fill_uniform(float* out, int64_t n, uint32_t seed, uint64_t offset, floa
 int svs_fill_tiles(float* mix, float* voc, int B, int H, int W, int64_t first_tile, hipStream_t stream);
 /* Dropout2d(0.5) keep-masks (model.py:83,89,95,101,107): out[b*C+c] in {0, 2}. */
 int svs_dropout_mask(float* out, int B, int C, int layer, uint32_t seed, int step, int rank, hipStream_t stream);
+/* The five decoder masks of one step in one launch: out = [B*256 | B*128 | B*64 | B*32 | B*16] floats, each block
+ * bit-identical to svs_dropout_mask(layer = 0..4) -- the layout svs_unet_train_* take as `drop`. */
+int svs_dropout_masks_all(float* out, int B, uint32_t seed, int step, int rank, hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Weight layouts.  Checkpoints keep torch's layouts (Conv2d (N,C,5,5), model.py:48; ConvTranspose2d

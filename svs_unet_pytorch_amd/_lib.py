@@ -32,6 +32,7 @@ _SIGS = {
     "svs_fill_uniform": (I, [P, L, U32, U64, F, F, P]),
     "svs_fill_tiles": (I, [P, P, I, I, I, L, P]),
     "svs_dropout_mask": (I, [P, I, I, I, U32, I, I, P]),
+    "svs_dropout_masks_all": (I, [P, I, U32, I, I, P]),
     "svs_pack_weight_gather": (I, [P, P, I, I, P]),
     "svs_pack_weight_parity": (I, [P, P, I, I, P]),
     "svs_bn_fold": (I, [P, P, P, P, P, F, P, P, I, P]),

@@ -225,13 +225,20 @@ extern "C" int svs_bn_stats(const float* raw, int64_t ldr, int64_t P, int C, voi
 extern "C" int svs_bn_finalize(const void* ws, int64_t P, int C, float eps, float momentum, float* running_mean,
                                float* running_var, int64_t* num_batches_tracked, float* save_mean, float* save_invstd,
                                hipStream_t stream) {
-  SVS_REQUIRE(ws && save_mean && save_invstd, "svs_bn_finalize: null pointer");
-  const int nb = red_blocks(P, C);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C / 4), dim3(256), 0, stream, (const float*)ws, nb, (long)P, C, eps,
-                     momentum, running_mean, running_var, (long long*)num_batches_tracked, save_mean, save_invstd);
+  return svs_bn_finalize_run(ws, red_blocks(P, C), P, C, eps, momentum, running_mean, running_var,
+                             (long long*)num_batches_tracked, save_mean, save_invstd, stream);
+}
+
+int svs_bn_finalize_run(const void* partial, int nblk, long P, int C, float eps, float momentum, float* running_mean,
+                        float* running_var, long long* nbt, float* save_mean, float* save_invstd, hipStream_t stream) {
+  SVS_REQUIRE(partial && save_mean && save_invstd && nblk > 0 && C % 4 == 0, "svs_bn_finalize: bad arguments");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C / 4), dim3(256), 0, stream, (const float*)partial, nblk, P, C, eps,
+                     momentum, running_mean, running_var, nbt, save_mean, save_invstd);
   SVS_CHECK_LAUNCH("bn_finalize");
   return SVS_OK;
 }
+
+size_t svs_bn_partial_floats(long P, int C) { return (size_t)red_blocks(P, C) * 2 * C; }
 
 extern "C" int svs_bn_act_apply(const float* raw, int64_t ldr, int64_t P, int C, int64_t pixels_per_sample,
                                 const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
@@ -249,7 +256,7 @@ extern "C" int svs_bn_act_apply(const float* raw, int64_t ldr, int64_t P, int C,
 int svs_bn_bwd_run(const float* dy, long lddy, const float* raw, long ldr, long P, int C, long pixels_per_sample,
                    const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, float slope,
                    const float* drop, float* d_raw, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes,
-                   hipStream_t stream);
+                   hipStream_t stream, float* dbias_partial, SvsSumJobs* defer);
 __global__ void channel_sum_finalize_kernel(const float* __restrict__ partial, int nblk, int C, float* out);
 
 extern "C" int svs_bn_bwd(const float* dy, int64_t lddy, const float* raw, int64_t ldr, int64_t P, int C,
@@ -257,13 +264,13 @@ extern "C" int svs_bn_bwd(const float* dy, int64_t lddy, const float* raw, int64
                           const float* save_invstd, float slope, const float* drop, float* d_raw, float* dgamma,
                           float* dbeta, void* ws, size_t ws_bytes, hipStream_t stream) {
   return svs_bn_bwd_run(dy, lddy, raw, ldr, P, C, pixels_per_sample, gamma, beta, save_mean, save_invstd, slope, drop, d_raw,
-                        dgamma, dbeta, nullptr, ws, ws_bytes, stream);
+                        dgamma, dbeta, nullptr, ws, ws_bytes, stream, nullptr, nullptr);
 }
 
 int svs_bn_bwd_run(const float* dy, long lddy, const float* raw, long ldr, long P, int C, long pixels_per_sample,
                    const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, float slope,
                    const float* drop, float* d_raw, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes,
-                   hipStream_t stream) {
+                   hipStream_t stream, float* dbias_partial, SvsSumJobs* defer) {
   int rc = check_bn("svs_bn_bwd", raw, ldr, P, C);
   if (rc) return rc;
   SVS_REQUIRE(dy && d_raw && lddy >= C && lddy % 4 == 0 && svs_aligned16(dy) && svs_aligned16(d_raw), "svs_bn_bwd: bad gradient view");
@@ -279,11 +286,17 @@ int svs_bn_bwd_run(const float* dy, long lddy, const float* raw, long ldr, long 
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C / 4), dim3(256), 0, stream, (const float*)partial, nb, (long)P, C,
                      gamma, save_invstd, dgamma, dbeta, coef);
   SVS_CHECK_LAUNCH("bn_bwd_finalize");
-  // the apply pass reuses the partial buffer of the reduce pass (already consumed by the finalize kernel)
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nb), dim3(256), 0, stream, p, (const float*)coef, d_raw, dbias ? partial : nullptr,
+  // the apply pass reuses the partial buffer of the reduce pass (already consumed by the finalize kernel) unless the
+  // caller keeps the bias-gradient partials for a deferred, batched final pass
+  const bool deferred = dbias && dbias_partial && defer && defer->njobs < 12;
+  float* bpart = deferred ? dbias_partial : partial;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nb), dim3(256), 0, stream, p, (const float*)coef, d_raw, dbias ? bpart : nullptr,
                      (P + nb - 1) / nb);
   SVS_CHECK_LAUNCH("bn_bwd_apply");
-  if (dbias) {
+  if (deferred) {
+    const int j = defer->njobs++;
+    defer->partial[j] = bpart; defer->nblk[j] = nb; defer->C[j] = C; defer->out[j] = dbias;
+  } else if (dbias) {
     hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3(C / 4), dim3(256), 0, stream, (const float*)partial, nb, C, dbias);
     SVS_CHECK_LAUNCH("channel_sum_finalize");
   }
@@ -297,6 +310,24 @@ __global__ __launch_bounds__(256) void channel_sum_finalize_kernel(const float* 
   double s, ss;
   reduce_partials4(partial, nblk, C, blockIdx.x * 4, &s, &ss);
   if (threadIdx.x < 4) out[blockIdx.x * 4 + threadIdx.x] = (float)s;
+}
+
+// the same for several (partial, C, out) jobs in one launch: block -> (job, channel quad)
+__global__ __launch_bounds__(256) void channel_sum_finalize_multi_kernel(SvsSumJobs jobs) {
+  int blk = blockIdx.x, j = 0;
+  while (j < jobs.njobs - 1 && blk >= jobs.C[j] / 4) { blk -= jobs.C[j] / 4; ++j; }
+  double s, ss;
+  reduce_partials4(jobs.partial[j], jobs.nblk[j], jobs.C[j], blk * 4, &s, &ss);
+  if (threadIdx.x < 4) jobs.out[j][blk * 4 + threadIdx.x] = (float)s;
+}
+
+int svs_channel_sum_finalize_multi_run(const SvsSumJobs& jobs, hipStream_t stream) {
+  if (jobs.njobs <= 0) return SVS_OK;
+  int blocks = 0;
+  for (int j = 0; j < jobs.njobs; ++j) blocks += jobs.C[j] / 4;
+  hipLaunchKernelGGL(channel_sum_finalize_multi_kernel, dim3(blocks), dim3(256), 0, stream, jobs);
+  SVS_CHECK_LAUNCH("channel_sum_finalize_multi");
+  return SVS_OK;
 }
 
 int svs_channel_sum_run(const float* x, long ldx, long P, int C, float* out, void* ws, size_t ws_bytes, hipStream_t stream) {
@@ -635,6 +666,22 @@ extern "C" int svs_fill_tiles(float* mix, float* voc, int B, int H, int W, int64
 __global__ void dropout_mask_kernel(float* out, int n, uint32_t seed, uint64_t offset) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = (float)(svs_u32(seed, offset + (uint64_t)i) >> 31) * 2.f;
+}
+// all five decoder masks in one launch: out = [B*256 | B*128 | B*64 | B*32 | B*16], each as svs_dropout_mask draws it
+__global__ void dropout_masks_all_kernel(float* out, int B, uint32_t seed, int step, int rank) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * 496) return;
+  int layer = 0, base = 0, c = 256;
+  while (i >= base + B * c) { base += B * c; c >>= 1; ++layer; }
+  const uint64_t off = ((uint64_t)layer << 56) | ((uint64_t)(rank & 0xFF) << 48) | ((uint64_t)(step & 0xFFFFFF) << 24);
+  out[i] = (float)(svs_u32(seed, off + (uint64_t)(i - base)) >> 31) * 2.f;
+}
+extern "C" int svs_dropout_masks_all(float* out, int B, uint32_t seed, int step, int rank, hipStream_t stream) {
+  SVS_REQUIRE(out && B > 0 && (long)B * 496 < (1L << 31), "svs_dropout_masks_all: bad arguments");
+  const int n = B * 496;
+  hipLaunchKernelGGL(dropout_masks_all_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, out, B, seed, step, rank);
+  SVS_CHECK_LAUNCH("dropout_masks_all");
+  return SVS_OK;
 }
 extern "C" int svs_dropout_mask(float* out, int B, int C, int layer, uint32_t seed, int step, int rank, hipStream_t stream) {
   SVS_REQUIRE(out && B > 0 && C > 0 && layer >= 0 && layer < 5, "svs_dropout_mask: bad arguments");

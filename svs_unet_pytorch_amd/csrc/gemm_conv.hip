@@ -560,14 +560,19 @@ __global__ __launch_bounds__(256) void parity_window_kernel(ConvGemmArgs p) {
   }
 }
 
-// out[pix][n] = epi(sum_z slab[z][pix][n] + bias[n])
+// out[pix][n] = epi(sum_z slab[z][pix][n] + bias[n]).  With `stats` the block also leaves the per-channel sum and
+// sum of squares of the values it wrote in stats[blk][2][N] (the layout of svs_bn_stats' partials), so the
+// BatchNorm statistics of a split-K layer need no pass of their own over the output (requires 256 % (N/4) == 0:
+// a thread then keeps the same four channels for the whole grid-stride loop).
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __restrict__ slab, int ksplit, long P, int N,
                                                               const float* __restrict__ bias,
                                                               const float* __restrict__ scale,
                                                               const float* __restrict__ shift, float slope,
-                                                              float* y, long ldy, int accumulate) {
+                                                              float* y, long ldy, int accumulate, float* __restrict__ stats) {
+  __shared__ f32x4 red[2][256];
   const long total4 = P * N / 4;
   const long stride = P * N;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
     const long e = i * 4;
     const long pix = e / N;
@@ -587,6 +592,20 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
       s[k] = v;
     }
     *(f32x4*)dst = s;
+    s0 += s;
+    s1 += s * s;
+  }
+  if (!stats) return;
+  const int G = N >> 2, PL = 256 / G, t = threadIdx.x;
+  red[0][t] = s0;
+  red[1][t] = s1;
+  __syncthreads();
+  if (t < G) {
+    f32x4 a = red[0][t], b = red[1][t];
+    for (int j = 1; j < PL; ++j) { a += red[0][j * G + t]; b += red[1][j * G + t]; }
+    float* out = stats + (long)blockIdx.x * 2 * N;
+    *(f32x4*)(out + t * 4) = a;
+    *(f32x4*)(out + N + t * 4) = b;
   }
 }
 
@@ -672,7 +691,8 @@ static int use_parity_window(int mode, int B, int H, int W, int C, int N, long l
 int svs_conv_gemm_run(int mode, const float* x, long ldx, int B, int H, int W, int C, const float* wp,
                       const float* bias, const float* scale, const float* shift, float slope, float* y, long ldy,
                       int Ho, int Wo, int N, int accumulate, void* ws, size_t ws_bytes, hipStream_t stream,
-                      const char* who) {
+                      const char* who, float* stats, int stats_cap, int* stats_nblk) {
+  if (stats_nblk) *stats_nblk = 0;
   int rc = check_gemm_args(who, x, ldx, B, H, W, C, wp, y, ldy, Ho, Wo, N);
   if (rc) return rc;
   long Mmax;
@@ -756,9 +776,13 @@ int svs_conv_gemm_run(int mode, const float* x, long ldx, int B, int H, int W, i
     const long total4 = P * N / 4;
     int grid = (int)((total4 + 255) / 256);
     if (grid > 2048) grid = 2048;
+    // fused BatchNorm statistics: stats[grid][2][N] must fit the caller's buffer (stats_cap rows)
+    const bool fuse = stats && stats_nblk && stats_cap > 0 && N % 4 == 0 && N <= 1024 && 256 % (N / 4) == 0 && !scale && !accumulate;
+    if (fuse && grid > stats_cap) grid = stats_cap;
     hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(grid), dim3(256), 0, stream, a.slab, pl.ksplit, P, N, bias, scale,
-                       shift, slope, y, ldy, accumulate);
+                       shift, slope, y, ldy, accumulate, fuse ? stats : nullptr);
     SVS_CHECK_LAUNCH("splitk_epilogue");
+    if (fuse) *stats_nblk = grid;
   }
   return SVS_OK;
 }

@@ -7,7 +7,14 @@ enum { SVS_MODE_GATHER = 0, SVS_MODE_PARITY = 1 };
 int svs_conv_gemm_run(int mode, const float* x, long ldx, int B, int H, int W, int C, const float* wp,
                       const float* bias, const float* scale, const float* shift, float slope, float* y, long ldy,
                       int Ho, int Wo, int N, int accumulate, void* ws, size_t ws_bytes, hipStream_t stream,
-                      const char* who);
+                      const char* who, float* stats = nullptr, int stats_cap = 0, int* stats_nblk = nullptr);
+// stats / stats_cap / stats_nblk: when the planner splits K, the epilogue kernel also writes svs_bn_stats-style
+// partials of the output into stats[<= stats_cap][2][N] and reports the number of rows (0: not produced).
+int svs_bn_finalize_run(const void* partial, int nblk, long P, int C, float eps, float momentum, float* running_mean,
+                        float* running_var, long long* nbt, float* save_mean, float* save_invstd, hipStream_t stream);
+struct SvsSumJobs { int njobs; const float* partial[12]; int nblk[12]; int C[12]; float* out[12]; };
+int svs_channel_sum_finalize_multi_run(const SvsSumJobs& jobs, hipStream_t stream);
+size_t svs_bn_partial_floats(long P, int C);
 size_t svs_conv_gemm_workspace(int mode, int B, int H, int W, int C, int Ho, int Wo, int N);
 
 int svs_wgrad_gemm_run(const float* s, long lds, int B, int Hs, int Ws, int Cs, const float* l, long ldl, int Hl,
@@ -39,7 +46,10 @@ int svs_pack_all_run(SvsPackJobs& jobs, hipStream_t stream);
 int svs_bn_bwd_run(const float* dy, long lddy, const float* raw, long ldr, long P, int C, long pixels_per_sample,
                    const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, float slope,
                    const float* drop, float* d_raw, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes,
-                   hipStream_t stream);
+                   hipStream_t stream, float* dbias_partial = nullptr, SvsSumJobs* defer = nullptr);
+// dbias_partial + defer: the per-block sums of d_raw go to dbias_partial (svs_bn_partial_floats(P, C) floats, must
+// stay untouched until the deferred pass) and the final reduction into dbias is appended to *defer instead of being
+// launched -- the caller runs svs_channel_sum_finalize_multi_run once for all layers.
 
 int svs_conv_gemm_describe(int mode, int B, int H, int W, int C, int Ho, int Wo, int N, long ldx, char* buf, size_t n);
 int svs_wgrad_gemm_describe(int B, int Hs, int Ws, int Cs, int Cl, char* buf, size_t n);

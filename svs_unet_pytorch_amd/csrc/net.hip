@@ -312,9 +312,11 @@ struct TrainWs {
   float* dcat[6]; float* dc6;
   float* d_raw; float* d_logit; float* mask;
   float* bnws; size_t bnws_bytes;
+  float* dbias_part[11];                  // per-layer partial sums of d_raw (bias gradients), reduced in one batched pass
   float* scratch; size_t scratch_bytes;
   size_t total;
 };
+#define SVS_FUSED_STATS_ROWS 512          // rows of BatchNorm partials the split-K epilogue may write into bnws
 static TrainWs train_layout(const Geo& g, void* ws) {
   TrainWs t{};
   Arena a{(char*)ws, 0};
@@ -335,8 +337,13 @@ static TrainWs train_layout(const Geo& g, void* ws) {
   t.mask = a.take((size_t)g.P[0]);
   size_t bb = 0;
   for (int k = 1; k <= 6; ++k) { size_t s = svs_bn_workspace_bytes(g.P[k], CH[k]); if (s > bb) bb = s; }
+  if (bb < (size_t)SVS_FUSED_STATS_ROWS * 2 * 512 * sizeof(float)) bb = (size_t)SVS_FUSED_STATS_ROWS * 2 * 512 * sizeof(float);
   t.bnws_bytes = bb + 4096;
   t.bnws = a.take(t.bnws_bytes / sizeof(float));
+  for (int l = 0; l < 11; ++l) {
+    const int lvl = (l < 6) ? l + 1 : 5 - (l - 6);
+    t.dbias_part[l] = a.take(svs_bn_partial_floats(g.P[lvl], bn_channels(l)));
+  }
   size_t sb = 4096;
   auto upd = [&](size_t s) { if (s > sb) sb = s; };
   for (int k = 2; k <= 6; ++k) {
@@ -394,6 +401,7 @@ static int train_forward_impl(const ParamView& v, float* bn_buffers, int64_t* nb
                               const Geo& g, const TrainWs& t, float* mask, hipStream_t stream) {
   const int B = g.B;
   int rc;
+  const int fused_rows = getenv("SVS_TRAIN_UNFUSED") ? 0 : SVS_FUSED_STATS_ROWS;     // A/B switch
   // weight packings for this step (weights change every optimiser step)
   {
     SvsPackJobs jobs{};
@@ -413,14 +421,22 @@ static int train_forward_impl(const ParamView& v, float* bn_buffers, int64_t* nb
     const View xi = (k == 1) ? View{const_cast<float*>(mix), 1} : cat_half(t.cat, g, k - 1, 1);
     const float* x = xi.p; const long ldx = xi.ld;
     const float* wp = (k == 1) ? v.w[0] : t.wfwd[k - 1];
-    rc = svs_enc_block_fwd(x, ldx, B, g.h[k - 1], g.w[k - 1], CH[k - 1], wp, v.b[k - 1], nullptr, nullptr, 0.f, t.raw_e[k],
-                           CH[k], CH[k], 0, t.scratch, t.scratch_bytes, stream);
+    int stat_rows = 0;                       // > 0: the split-K epilogue already left the BatchNorm partials in bnws
+    if (k == 1) rc = svs_enc_block_fwd(x, ldx, B, g.h[0], g.w[0], 1, wp, v.b[0], nullptr, nullptr, 0.f, t.raw_e[1], CH[1], CH[1], 0,
+                                       t.scratch, t.scratch_bytes, stream);
+    else rc = svs_conv_gemm_run(SVS_MODE_GATHER, x, ldx, B, g.h[k - 1], g.w[k - 1], CH[k - 1], wp, v.b[k - 1], nullptr, nullptr, 0.f,
+                                t.raw_e[k], CH[k], g.h[k], g.w[k], CH[k], 0, t.scratch, t.scratch_bytes, stream, "conv forward",
+                                t.bnws, fused_rows, &stat_rows);
     if (rc) return rc;
     const int l = k - 1;
-    if ((rc = svs_bn_stats(t.raw_e[k], CH[k], g.P[k], CH[k], t.bnws, t.bnws_bytes, stream))) return rc;
-    if ((rc = svs_bn_finalize(t.bnws, g.P[k], CH[k], BN_EPS, BN_MOMENTUM, bn_buffers ? bn_buffers + svs_unet_buffer_offset(l, 0) : nullptr,
-                              bn_buffers ? bn_buffers + svs_unet_buffer_offset(l, 1) : nullptr, nbt ? nbt + l : nullptr,
-                              t.mean[l], t.invstd[l], stream))) return rc;
+    if (!stat_rows) {
+      if ((rc = svs_bn_stats(t.raw_e[k], CH[k], g.P[k], CH[k], t.bnws, t.bnws_bytes, stream))) return rc;
+      stat_rows = (int)(svs_bn_partial_floats(g.P[k], CH[k]) / (2 * CH[k]));
+    }
+    if ((rc = svs_bn_finalize_run(t.bnws, stat_rows, g.P[k], CH[k], BN_EPS, BN_MOMENTUM,
+                                  bn_buffers ? bn_buffers + svs_unet_buffer_offset(l, 0) : nullptr,
+                                  bn_buffers ? bn_buffers + svs_unet_buffer_offset(l, 1) : nullptr,
+                                  nbt ? (long long*)(nbt + l) : nullptr, t.mean[l], t.invstd[l], stream))) return rc;
     const View yo = (k == 6) ? View{t.c6, 512} : cat_half(t.cat, g, k, 1);
     float* y = yo.p; const long ldy = yo.ld;
     if ((rc = svs_bn_act_apply(t.raw_e[k], CH[k], g.P[k], CH[k], (long)g.h[k] * g.w[k], v.gamma[l], v.beta[l], t.mean[l],
@@ -431,13 +447,19 @@ static int train_forward_impl(const ParamView& v, float* bn_buffers, int64_t* nb
   for (int j = 0; j < 5; ++j) {
     const int lin = 6 - j, lout = 5 - j, l = 6 + j;
     const float* x = (j == 0) ? t.c6 : t.cat[lin];
-    rc = svs_dec_block_fwd(x, DEC_C[j], B, g.h[lin], g.w[lin], DEC_C[j], t.wfwd[l], v.b[l], nullptr, nullptr, 0.f,
-                           t.raw_d[j], DEC_N[j], g.h[lout], g.w[lout], DEC_N[j], 0, t.scratch, t.scratch_bytes, stream);
+    int stat_rows = 0;
+    rc = svs_conv_gemm_run(SVS_MODE_PARITY, x, DEC_C[j], B, g.h[lin], g.w[lin], DEC_C[j], t.wfwd[l], v.b[l], nullptr, nullptr, 0.f,
+                           t.raw_d[j], DEC_N[j], g.h[lout], g.w[lout], DEC_N[j], 0, t.scratch, t.scratch_bytes, stream,
+                           "deconv forward", t.bnws, fused_rows, &stat_rows);
     if (rc) return rc;
-    if ((rc = svs_bn_stats(t.raw_d[j], DEC_N[j], g.P[lout], DEC_N[j], t.bnws, t.bnws_bytes, stream))) return rc;
-    if ((rc = svs_bn_finalize(t.bnws, g.P[lout], DEC_N[j], BN_EPS, BN_MOMENTUM, bn_buffers ? bn_buffers + svs_unet_buffer_offset(l, 0) : nullptr,
-                              bn_buffers ? bn_buffers + svs_unet_buffer_offset(l, 1) : nullptr, nbt ? nbt + l : nullptr,
-                              t.mean[l], t.invstd[l], stream))) return rc;
+    if (!stat_rows) {
+      if ((rc = svs_bn_stats(t.raw_d[j], DEC_N[j], g.P[lout], DEC_N[j], t.bnws, t.bnws_bytes, stream))) return rc;
+      stat_rows = (int)(svs_bn_partial_floats(g.P[lout], DEC_N[j]) / (2 * DEC_N[j]));
+    }
+    if ((rc = svs_bn_finalize_run(t.bnws, stat_rows, g.P[lout], DEC_N[j], BN_EPS, BN_MOMENTUM,
+                                  bn_buffers ? bn_buffers + svs_unet_buffer_offset(l, 0) : nullptr,
+                                  bn_buffers ? bn_buffers + svs_unet_buffer_offset(l, 1) : nullptr,
+                                  nbt ? (long long*)(nbt + l) : nullptr, t.mean[l], t.invstd[l], stream))) return rc;
     const View yo = cat_half(t.cat, g, lout, 0);
     if ((rc = svs_bn_act_apply(t.raw_d[j], DEC_N[j], g.P[lout], DEC_N[j], (long)g.h[lout] * g.w[lout], v.gamma[l], v.beta[l],
                                t.mean[l], t.invstd[l], 0.f, dp, yo.p, yo.ld, stream))) return rc;
@@ -455,6 +477,8 @@ static int train_backward_impl(const ParamView& v, float* grads, const float* mi
   const int B = g.B;
   int rc;
   auto G = [&](int idx) { return grads + svs_unet_param_offset(idx); };
+  SvsSumJobs sums{};                         // bias-gradient reductions, run as one batched launch per half
+  const bool unfused = getenv("SVS_TRAIN_UNFUSED") != nullptr;     // A/B switch: one launch per reduction, as before
   if (parts & 1) {
   // deconv6 (model.py:109,198): dw, db, dx -> dcat[1]
   const long half1 = g.P[1] * 16;     // level 1 is planar (cat_half)
@@ -472,7 +496,7 @@ static int train_backward_impl(const ParamView& v, float* grads, const float* mi
     const View dyv = cat_half(t.dcat, g, lout, 0);
     rc = svs_bn_bwd_run(dyv.p, dyv.ld, t.raw_d[j], N, g.P[lout], N, (long)g.h[lout] * g.w[lout], v.gamma[l], v.beta[l],
                         t.mean[l], t.invstd[l], 0.f, drop ? drop + drop_off[j] : nullptr, t.d_raw, G(24 + 4 * j + 2), G(24 + 4 * j + 3),
-                        G(24 + 4 * j + 1), t.bnws, t.bnws_bytes, stream);          // + bias gradient (sum of d_raw)
+                        G(24 + 4 * j + 1), t.bnws, t.bnws_bytes, stream, unfused ? nullptr : t.dbias_part[l], &sums);   // + bias gradient (sum of d_raw)
     if (rc) return rc;
     if ((rc = svs_dec_block_bwd_weight(x, C, B, g.h[lin], g.w[lin], C, t.d_raw, N, g.h[lout], g.w[lout], N, G(24 + 4 * j), nullptr,
                                        t.scratch, t.scratch_bytes, stream))) return rc;
@@ -480,6 +504,8 @@ static int train_backward_impl(const ParamView& v, float* grads, const float* mi
     if ((rc = svs_dec_block_bwd_data(t.d_raw, N, B, g.h[lout], g.w[lout], N, t.wbwd[l], dx, C, g.h[lin], g.w[lin], C, 0,
                                      t.scratch, t.scratch_bytes, stream))) return rc;
   }
+  if ((rc = svs_channel_sum_finalize_multi_run(sums, stream))) return rc;    // the five decoder bias gradients
+  sums.njobs = 0;
   }
   if (!(parts & 2)) return SVS_OK;
   // encoders 6..1
@@ -488,7 +514,8 @@ static int train_backward_impl(const ParamView& v, float* grads, const float* mi
     const View dyv = (k == 6) ? View{t.dc6, 512} : cat_half(t.dcat, g, k, 1);
     const float* dy = dyv.p; const long lddy = dyv.ld;
     rc = svs_bn_bwd_run(dy, lddy, t.raw_e[k], N, g.P[k], N, (long)g.h[k] * g.w[k], v.gamma[l], v.beta[l], t.mean[l], t.invstd[l],
-                        LEAKY, nullptr, t.d_raw, G(4 * l + 2), G(4 * l + 3), G(4 * l + 1), t.bnws, t.bnws_bytes, stream);
+                        LEAKY, nullptr, t.d_raw, G(4 * l + 2), G(4 * l + 3), G(4 * l + 1), t.bnws, t.bnws_bytes, stream,
+                        unfused ? nullptr : t.dbias_part[l], &sums);
     if (rc) return rc;
     const View xi = (k == 1) ? View{const_cast<float*>(mix), 1} : cat_half(t.cat, g, k - 1, 1);
     const float* x = xi.p; const long ldx = xi.ld;
@@ -501,7 +528,7 @@ static int train_backward_impl(const ParamView& v, float* grads, const float* mi
                                        t.scratch, t.scratch_bytes, stream))) return rc;
     }
   }
-  return SVS_OK;
+  return svs_channel_sum_finalize_multi_run(sums, stream);                    // the six encoder bias gradients
 }
 
 static int check_train_ws(const char* who, const Geo& g, void* ws, size_t ws_bytes, TrainWs& t) {

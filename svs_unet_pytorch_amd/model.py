@@ -318,11 +318,8 @@ class UNet(nn.Module):
                 return None
             return torch.cat([m.reshape(-1).to(self._flat.device, torch.float32) for m in self._injected_masks])
         out = torch.empty(B * sum(c for _, c in DEC_IO[:5]), dtype=torch.float32, device=self._flat.device)
-        off = 0
-        for layer, (_, c) in enumerate(DEC_IO[:5]):
-            check(lib().svs_dropout_mask(out.data_ptr() + 4 * off, B, c, layer, self.dropout_seed, self.dropout_step,
-                                         self.rank, _lib.stream_ptr()), "svs_dropout_mask")
-            off += B * c
+        check(lib().svs_dropout_masks_all(out.data_ptr(), B, self.dropout_seed, self.dropout_step, self.rank, _lib.stream_ptr()),
+              "svs_dropout_masks_all")
         self.dropout_step += 1
         return out
 

@@ -442,6 +442,9 @@ def test_synth_matches_host(report):
         out = torch.empty(mk.shape, device=DEV)
         _lib.check(L().svs_dropout_mask(out.data_ptr(), mk.shape[0], mk.shape[1], layer, 99, 3, 2, S()))
         assert np.array_equal(out.cpu().numpy(), mk)
+    flat = torch.empty(6 * 496, device=DEV)                     # the five masks in one launch: same bits, same layout
+    _lib.check(L().svs_dropout_masks_all(flat.data_ptr(), 6, 99, 3, 2, S()))
+    assert np.array_equal(flat.cpu().numpy(), np.concatenate([m.reshape(-1) for m in masks]))
 
 
 def test_stft_istft(report):
