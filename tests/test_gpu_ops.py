@@ -92,8 +92,11 @@ ENC_CASES = [
 ]
 
 
+@pytest.mark.parametrize("rows", ["bhw", "whb"])          # GEMM row order: planner default / batch-innermost + tap skipping forced
 @pytest.mark.parametrize("B,H,W,C,N", ENC_CASES)
-def test_enc_block_fwd(B, H, W, C, N, report):
+def test_enc_block_fwd(B, H, W, C, N, rows, report, monkeypatch):
+    if rows == "whb":
+        monkeypatch.setenv("SVS_CONV_SKIP", "2")
     x = rnd((B, C, H, W), 10)
     w = rnd((N, C, 5, 5), 11, -0.1, 0.1)
     b = rnd((N,), 12)
@@ -110,7 +113,7 @@ def test_enc_block_fwd(B, H, W, C, N, report):
     torch.cuda.synchronize()
     assert torch.all(y[..., :N] == 7.0), "wrote outside its channel slice"
     e = relerr(nchw(y[..., N:]), want)
-    assert report(f"enc_fwd raw B{B} {H}x{W} C{C} N{N}", e, 2e-5)
+    assert report(f"enc_fwd[{rows}] raw B{B} {H}x{W} C{C} N{N}", e, 2e-5)
     # eval epilogue: scale/shift + leaky, bias folded by the caller -> here bias=None
     sc, sh = rnd((N,), 13, 0.5, 1.5), rnd((N,), 14)
     want2 = F.leaky_relu(F.conv2d(x.double(), w.double(), None, stride=2, padding=2) * sc.double()[None, :, None, None]
@@ -120,7 +123,7 @@ def test_enc_block_fwd(B, H, W, C, N, report):
     _lib.check(L().svs_enc_block_fwd(xd.data_ptr(), C, B, H, W, C, wp.data_ptr(), None, scd.data_ptr(), shd.data_ptr(), 0.2,
                                      y2.data_ptr(), N, N, 0, ws.data_ptr(), ws.numel(), S()))
     e = relerr(nchw(y2), want2)
-    assert report(f"enc_fwd epi B{B} {H}x{W} C{C} N{N}", e, 2e-5)
+    assert report(f"enc_fwd[{rows}] epi B{B} {H}x{W} C{C} N{N}", e, 2e-5)
     # accumulate
     _lib.check(L().svs_enc_block_fwd(xd.data_ptr(), C, B, H, W, C, wp.data_ptr(), None, scd.data_ptr(), shd.data_ptr(), 0.2,
                                      y2.data_ptr(), N, N, 1, ws.data_ptr(), ws.numel(), S()))
@@ -154,8 +157,11 @@ DEC_CASES = [
 ]
 
 
+@pytest.mark.parametrize("rows", ["bhw", "whb"])
 @pytest.mark.parametrize("B,H,W,C,N,Ho,Wo", DEC_CASES)
-def test_dec_block_fwd(B, H, W, C, N, Ho, Wo, report):
+def test_dec_block_fwd(B, H, W, C, N, Ho, Wo, rows, report, monkeypatch):
+    if rows == "whb":
+        monkeypatch.setenv("SVS_CONV_SKIP", "2")
     x = rnd((B, C, H, W), 30)
     w = rnd((C, N, 5, 5), 31, -0.1, 0.1)
     b = rnd((N,), 32)
@@ -170,7 +176,7 @@ def test_dec_block_fwd(B, H, W, C, N, Ho, Wo, report):
                                      y.data_ptr(), 2 * N, Ho, Wo, N, 0, ws.data_ptr(), ws.numel(), S()))
     torch.cuda.synchronize()
     assert torch.all(y[..., N:] == -3.0)
-    assert report(f"dec_fwd raw B{B} {H}x{W}->{Ho}x{Wo} C{C} N{N}", relerr(nchw(y[..., :N]), want), 2e-5)
+    assert report(f"dec_fwd[{rows}] raw B{B} {H}x{W}->{Ho}x{Wo} C{C} N{N}", relerr(nchw(y[..., :N]), want), 2e-5)
     sc, sh = rnd((N,), 33, 0.5, 1.5), rnd((N,), 34)
     want2 = F.relu(F.conv_transpose2d(x.double(), w.double(), None, stride=2, padding=2, output_padding=op)
                    * sc.double()[None, :, None, None] + sh.double()[None, :, None, None])
@@ -178,7 +184,7 @@ def test_dec_block_fwd(B, H, W, C, N, Ho, Wo, report):
     scd, shd = sc.to(DEV), sh.to(DEV)
     _lib.check(L().svs_dec_block_fwd(xd.data_ptr(), C, B, H, W, C, wp.data_ptr(), None, scd.data_ptr(), shd.data_ptr(), 0.0,
                                      y2.data_ptr(), N, Ho, Wo, N, 0, ws.data_ptr(), ws.numel(), S()))
-    assert report(f"dec_fwd epi B{B} {H}x{W}->{Ho}x{Wo} C{C} N{N}", relerr(nchw(y2), want2), 2e-5)
+    assert report(f"dec_fwd[{rows}] epi B{B} {H}x{W}->{Ho}x{Wo} C{C} N{N}", relerr(nchw(y2), want2), 2e-5)
 
 
 WINDOW_CASES = [
