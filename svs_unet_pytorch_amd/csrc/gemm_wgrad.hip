@@ -24,6 +24,7 @@ struct WgradArgs {
   float* slab;           // [ksplit][Cs][25*Cl]
   long pix_per_split;    // multiple of 16
   int ws_shift, hs_shift; // log2 of Ws / Hs when they are powers of two, else -1
+  int b_shift;            // SKIP kernels: log2(B)
 };
 
 template <int T> __device__ __forceinline__ void load_vec(const float* p, float (&f)[T]);
@@ -37,7 +38,11 @@ template <int T> __device__ __forceinline__ void store_vec(float* p, const float
 template <> __device__ __forceinline__ void store_vec<4>(float* p, const float (&f)[4]) { *(f32x4*)p = (f32x4){f[0], f[1], f[2], f[3]}; }
 template <> __device__ __forceinline__ void store_vec<2>(float* p, const float (&f)[2]) { *(float2*)p = make_float2(f[0], f[1]); }
 
-template <int BM, int BN, int WM, int WN>
+// SKIP = true (deep levels, B % 16 == 0, Ws a power of two): pixels are taken batch-innermost, k = (i*Ws + j)*B + b, so
+// the 16 pixels of a K-tile are the SAME position (i, j) of 16 images.  A tap that falls into the zero padding at
+// that position does so for the whole tile; a K-tile none of whose N-tile taps is inside the image is skipped
+// outright (about a third of the tiles on the 8x2 level).  The per-tile pixel decode also becomes scalar.
+template <int BM, int BN, int WM, int WN, bool SKIP = false>
 __global__ __launch_bounds__(256) void wgrad_gemm_kernel(WgradArgs p) {
   constexpr int TM = BM / WM / 16;
   constexpr int TN = BN / WN / 16;
@@ -62,6 +67,7 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(WgradArgs p) {
   long p_end = p_begin + p.pix_per_split;
   if (p_end > P) p_end = P;
 
+  constexpr unsigned OOB = 0x80000000u;
   // fixed (k-row, chunk) assignments
   int ak[RA], ac[RA]; bool aok[RA];
 #pragma unroll
@@ -111,13 +117,68 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(WgradArgs p) {
   // SIMD): A rows have a fixed per-thread byte offset plus a per-tile scalar offset; B rows a 32-bit offset from
   // the incremental (b,i,j); a row outside the image / the split / the matrix is pointed past num_records and
   // reads zeros.
-  constexpr unsigned OOB = 0x80000000u;
   unsigned a_voff[RA];
 #pragma unroll
   for (int r = 0; r < RA; ++r) a_voff[r] = aok[r] ? (unsigned)(((long)ak[r] * p.lds + cs0 + ac[r] * 4) * 4) : OOB;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.s + p_begin * p.lds), 0, OOB, 0x00020000);
   const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void*)p.l, 0, OOB, 0x00020000);
+  // SKIP addressing: thread-constant byte offsets + one scalar offset per tile (position and first image of the tile)
+  const int HsWs = p.Hs * p.Ws, HlWl = p.Hl * p.Wl;
+  unsigned a_voff_s[RA], b_voff_s[RB];
+  int tap_lo = 0, tap_hi = 0;
+  if (SKIP) {
+#pragma unroll
+    for (int r = 0; r < RA; ++r) a_voff_s[r] = aok[r] ? (unsigned)((((long)ak[r] * HsWs) * p.lds + cs0 + ac[r] * 4) * 4) : OOB;
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+      b_voff_s[r] = (unsigned)((((long)bk[r] * HlWl + bkh[r] * p.Wl + bkw[r]) * p.ldl + bcl[r]) * 4);
+    tap_lo = n0 / p.Cl;
+    const int nlast = (n0 + BN - 1 < Ntot - 1) ? n0 + BN - 1 : Ntot - 1;
+    tap_hi = nlast / p.Cl;
+  }
+  // L is read relative to pixel (-2, -2) so that every thread-constant offset above is >= 0
+  const __amdgpu_buffer_rsrc_t rs_all = __builtin_amdgcn_make_buffer_rsrc((void*)p.s, 0, OOB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rl_sh = __builtin_amdgcn_make_buffer_rsrc((void*)(p.l - (2L * p.Wl + 2) * p.ldl), 0, OOB, 0x00020000);
+  auto position = [&](int pk, int& i, int& j, int& b0) {       // scalar: B and Ws are powers of two here
+    const int pos = pk >> p.b_shift;
+    b0 = pk & (p.B - 1);
+    i = pos >> p.ws_shift;
+    j = pos & (p.Ws - 1);
+  };
+  auto first_valid = [&](int pk) -> int {  // first K-tile >= pk (< p_end) with a tap of this N-tile inside the image
+    if (!SKIP) return pk;
+    while (pk < (int)p_end) {
+      int i, j, b0;
+      position(pk, i, j, b0);
+      bool any = false;
+      for (int tp = tap_lo; tp <= tap_hi; ++tp) {
+        const int kh = tp / 5, kw = tp - kh * 5;
+        any = any || ((unsigned)(2 * i - 2 + kh) < (unsigned)p.Hl && (unsigned)(2 * j - 2 + kw) < (unsigned)p.Wl);
+      }
+      if (any) return pk;
+      pk = ((pk >> p.b_shift) + 1) << p.b_shift;       // next position
+    }
+    return (int)p_end;
+  };
   f32x4 ra[RA], rb[RB];
+  auto load_tile_skip = [&](int pk) {
+    int i, j, b0;
+    position(pk, i, j, b0);
+    const int soff_a = __builtin_amdgcn_readfirstlane((int)((((long)b0 * HsWs + (i * p.Ws + j)) * p.lds) * 4));
+    const int soff_b = __builtin_amdgcn_readfirstlane((int)((((long)b0 * HlWl + 2 * i * p.Wl + 2 * j) * p.ldl) * 4));
+    const int left = (int)p_end - pk;
+#pragma unroll
+    for (int r = 0; r < RA; ++r) {
+      const unsigned vo = ak[r] < left ? a_voff_s[r] : OOB;
+      ra[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_all, (int)vo, soff_a, 0));
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const int ih = 2 * i - 2 + bkh[r], iw = 2 * j - 2 + bkw[r];
+      const bool ok = bok[r] && bk[r] < left && (unsigned)ih < (unsigned)p.Hl && (unsigned)iw < (unsigned)p.Wl;
+      rb[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rl_sh, (int)(ok ? b_voff_s[r] : OOB), soff_b, 0));
+    }
+  };
   auto load_tile = [&](long pk) {      // must be called with pk advancing by 16 from p_begin
     const int soff_a = (int)((pk - p_begin) * p.lds * 4);
     const int left = (int)(p_end - pk);          // rows of this tile inside the split (16 except in its last tile)
@@ -150,16 +211,18 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(WgradArgs p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  if (p_begin < p_end) {
-    load_tile(p_begin);
+  int pk = first_valid((int)p_begin);
+  if (pk < (int)p_end) {
+    if (SKIP) load_tile_skip(pk); else load_tile(pk);
     store_tile(0);
   }
   __syncthreads();
-  int it = 0;
-  for (long pk = p_begin; pk < p_end; pk += 16, ++it) {
+  for (int it = 0; pk < (int)p_end; ++it) {
     const int buf = it & 1;
-    const bool more = pk + 16 < p_end;
-    if (more) load_tile(pk + 16);
+    const int pkn = first_valid(pk + 16);
+    const bool more = pkn < (int)p_end;
+    if (more) { if (SKIP) load_tile_skip(pkn); else load_tile(pkn); }
+    pk = pkn;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       // Interleaved tiles: MFMA tile i of this wave owns the rows {TM*r + i : r = 0..15} (and tile j the columns
@@ -275,7 +338,15 @@ int svs_wgrad_gemm_run(const float* s, long lds, int B, int Hs, int Ws, int Cs, 
   SVS_REQUIRE((long)B * Hl * Wl * ldl * 4 < (1L << 31) && (long)(pl.pps + 16) * lds * 4 < (1L << 31),
               "%s: operand views need 64-bit offsets; split the batch", who);
   dim3 grid((unsigned)(Cs / pl.BM), (unsigned)((25 * Cl + pl.BN - 1) / pl.BN), (unsigned)pl.ksplit);
-  switch (pl.cfg) {
+  // deep levels: batch-innermost pixels, K-tiles whose taps are all in the padding are skipped (wgrad_gemm_kernel)
+  const bool can_skip = B >= 16 && (B & (B - 1)) == 0 && a.ws_shift >= 0 && pl.cfg == 0 && Cl >= 32 &&
+                        (long)B * Hs * Ws * lds * 4 < (1L << 31);
+  int skip = can_skip && Ws <= 8;
+  if (const char* e = getenv("SVS_WGRAD_SKIP")) { const int f = atoi(e); skip = (f == 0) ? 0 : (f == 2) ? can_skip : skip; }   // sweeps, tests
+  if (skip) {
+    a.b_shift = log2_or_neg(B);
+    hipLaunchKernelGGL((wgrad_gemm_kernel<128, 128, 2, 2, true>), grid, dim3(256), 0, stream, a);
+  } else switch (pl.cfg) {
     case 0: hipLaunchKernelGGL((wgrad_gemm_kernel<128, 128, 2, 2>), grid, dim3(256), 0, stream, a); break;
     case 1: hipLaunchKernelGGL((wgrad_gemm_kernel<64, 128, 1, 4>), grid, dim3(256), 0, stream, a); break;
     default: hipLaunchKernelGGL((wgrad_gemm_kernel<32, 128, 1, 4>), grid, dim3(256), 0, stream, a); break;

@@ -301,6 +301,39 @@ def test_dec_block_bwd(B, H, W, C, N, Ho, Wo, report):
     assert report(f"dec_bwd_bias B{B} {H}x{W} C{C} N{N}", relerr(db, b.grad), 2e-5)
 
 
+@pytest.mark.parametrize("kind,B,H,W,C,N", [("enc", 16, 8, 4, 64, 128), ("enc", 32, 16, 16, 32, 128), ("dec", 16, 4, 2, 256, 128),
+                                            ("dec", 16, 8, 8, 128, 64)])
+def test_wgrad_padding_skip(kind, B, H, W, C, N, report, monkeypatch):
+    """Weight gradients with batch-innermost pixels and padding-only K-tiles skipped (forced on small shapes), against
+    torch fp64; strided operand views."""
+    monkeypatch.setenv("SVS_WGRAD_SKIP", "2")
+    if kind == "enc":
+        x = rnd((B, C, H, W), 80).double()
+        w = rnd((N, C, 5, 5), 81, -0.1, 0.1).double().requires_grad_(True)
+        y = F.conv2d(x, w, None, stride=2, padding=2)
+    else:
+        x = rnd((B, C, H, W), 80).double()
+        w = rnd((C, N, 5, 5), 81, -0.1, 0.1).double().requires_grad_(True)
+        y = F.conv_transpose2d(x, w, None, stride=2, padding=2, output_padding=1)
+    dy = rnd(tuple(y.shape), 83)
+    y.backward(dy.double())
+    Ho, Wo = y.shape[2], y.shape[3]
+    dyd = torch.full((B, Ho, Wo, N + 4), 9.0, device=DEV)
+    dyd[..., :N] = nhwc(dy).to(DEV)
+    xd = torch.full((B, H, W, C + 8), 9.0, device=DEV)
+    xd[..., :C] = nhwc(x.float()).to(DEV)
+    dw = torch.empty(tuple(w.shape), device=DEV)
+    if kind == "enc":
+        ws = ws_tensor(L().svs_block_bwd_weight_workspace_bytes(B, Ho, Wo, N, C))
+        _lib.check(L().svs_enc_block_bwd_weight(dyd.data_ptr(), N + 4, B, Ho, Wo, N, xd.data_ptr(), C + 8, H, W, C, dw.data_ptr(), None,
+                                                ws.data_ptr(), ws.numel(), S()))
+    else:
+        ws = ws_tensor(L().svs_block_bwd_weight_workspace_bytes(B, H, W, C, N))
+        _lib.check(L().svs_dec_block_bwd_weight(xd.data_ptr(), C + 8, B, H, W, C, dyd.data_ptr(), N + 4, Ho, Wo, N, dw.data_ptr(), None,
+                                                ws.data_ptr(), ws.numel(), S()))
+    assert report(f"wgrad skip {kind} B{B} {H}x{W} C{C} N{N}", relerr(dw, w.grad), 2e-5)
+
+
 def test_single_channel_bwd(report):
     # conv1: dw, db ; deconv6: dw, db, dx
     B, H, W = 2, 64, 32
