@@ -12,6 +12,7 @@
 // Training additionally keeps the pre-BatchNorm ("raw") output of every block, the batch statistics,
 // both weight packings, and gradient images dcat[k] / dc6 of the same shapes.
 #include <math.h>
+#include <mutex>
 #include <stdarg.h>
 #include <string.h>
 
@@ -310,10 +311,11 @@ struct TrainWs {
   float* mean[11]; float* invstd[11];
   float* wfwd[12]; float* wbwd[12];       // packed weights (null where torch's layout is read directly)
   float* dcat[6]; float* dc6;
-  float* d_raw; float* d_logit; float* mask;
+  float* d_raw; float* d_raw2; float* d_logit; float* mask;   // d_raw2: second buffer so that the side stream's wgrad can trail
   float* bnws; size_t bnws_bytes;
   float* dbias_part[11];                  // per-layer partial sums of d_raw (bias gradients), reduced in one batched pass
   float* scratch; size_t scratch_bytes;
+  float* scratch2; size_t scratch2_bytes;     // split-K slabs of the weight-gradient GEMMs (side stream)
   size_t total;
 };
 #define SVS_FUSED_STATS_ROWS 512          // rows of BatchNorm partials the split-K epilogue may write into bnws
@@ -333,6 +335,7 @@ static TrainWs train_layout(const Geo& g, void* ws) {
   size_t dmax = 0;
   for (int k = 1; k <= 6; ++k) if ((size_t)g.P[k] * CH[k] > dmax) dmax = (size_t)g.P[k] * CH[k];
   t.d_raw = a.take(dmax);
+  t.d_raw2 = a.take(dmax);
   t.d_logit = a.take((size_t)g.P[0]);
   t.mask = a.take((size_t)g.P[0]);
   size_t bb = 0;
@@ -362,9 +365,43 @@ static TrainWs train_layout(const Geo& g, void* ws) {
   }
   t.scratch_bytes = sb;
   t.scratch = a.take(sb / sizeof(float) + 64);
+  size_t sb2 = svs_block_bwd_weight_workspace_bytes(B, g.h[1], g.w[1], 16, 1);
+  for (int k = 2; k <= 6; ++k) { const size_t s2 = svs_block_bwd_weight_workspace_bytes(B, g.h[k], g.w[k], CH[k], CH[k - 1]); if (s2 > sb2) sb2 = s2; }
+  for (int j = 0; j < 6; ++j) { const size_t s2 = svs_block_bwd_weight_workspace_bytes(B, g.h[6 - j], g.w[6 - j], DEC_C[j], DEC_N[j]); if (s2 > sb2) sb2 = s2; }
+  t.scratch2_bytes = sb2;
+  t.scratch2 = a.take(sb2 / sizeof(float) + 64);
   t.total = a.used;
   return t;
 }
+
+// ---- side stream ---------------------------------------------------------------------------------
+// In the backward pass the weight gradient of a layer (MFMA GEMM + slab reductions) depends only on that layer's
+// d_raw, while the chain that the next layer waits for is d_raw -> backward-data GEMM -> next BatchNorm backward
+// (bandwidth-bound passes).  The weight-gradient work therefore runs on a second HIP stream: its GEMMs fill the
+// machine while the main stream is in the bandwidth-bound BatchNorm passes and launch gaps, and its small reduction
+// kernels hide under the main stream's GEMMs.  Fork / join are events; d_raw is double-buffered so that the side
+// stream may trail the main one by a layer.  Results do not depend on the interleaving (no atomics anywhere).
+struct SideStream { hipStream_t s; hipEvent_t fork[4], done[4]; };
+static SideStream* g_side[64] = {};
+static std::mutex g_side_mutex;
+static SideStream* side_stream() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lock(g_side_mutex);
+  if (!g_side[dev]) {
+    SideStream* sd = new SideStream();
+    bool ok = hipStreamCreateWithFlags(&sd->s, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i < 4 && ok; ++i)
+      ok = hipEventCreateWithFlags(&sd->fork[i], hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&sd->done[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) { delete sd; return nullptr; }
+    g_side[dev] = sd;
+  }
+  return g_side[dev];
+}
+#define SVS_HIP(call)                                                                     \
+  do { hipError_t e_ = (call); if (e_ != hipSuccess) { svs_set_error("%s: %s", #call, hipGetErrorString(e_)); return SVS_ERR_INVALID; } } while (0)
+
 extern "C" size_t svs_unet_train_workspace_bytes(int B, int H, int W) {
   Geo g;
   if (make_geo(B, H, W, g)) return 0;
@@ -479,11 +516,39 @@ static int train_backward_impl(const ParamView& v, float* grads, const float* mi
   auto G = [&](int idx) { return grads + svs_unet_param_offset(idx); };
   SvsSumJobs sums{};                         // bias-gradient reductions, run as one batched launch per half
   const bool unfused = getenv("SVS_TRAIN_UNFUSED") != nullptr;     // A/B switch: one launch per reduction, as before
+  SideStream* sd = getenv("SVS_TRAIN_ONE_STREAM") ? nullptr : side_stream();   // A/B switch: everything on `stream`
+  const hipStream_t wstream = sd ? sd->s : stream;                  // where the weight gradients run
+  float* const wscratch = sd ? t.scratch2 : t.scratch;
+  const size_t wscratch_bytes = sd ? t.scratch2_bytes : t.scratch_bytes;
+  float* const draw[2] = {t.d_raw, sd ? t.d_raw2 : t.d_raw};
+  int nfork = 0;                             // forks so far in this call; fork n uses event slot n & 3 and d_raw buffer n & 1
+  // d_raw buffer of the next layer: the weight gradient that read it two layers ago must have finished
+  auto next_draw = [&]() -> float* {
+    if (sd && nfork >= 2 && hipStreamWaitEvent(stream, sd->done[(nfork - 2) & 3], 0) != hipSuccess) return nullptr;
+    return draw[nfork & 1];
+  };
+  auto fork = [&]() -> int {                 // the side stream may start once everything queued on `stream` so far is done
+    if (!sd) return SVS_OK;
+    SVS_HIP(hipEventRecord(sd->fork[nfork & 3], stream));
+    SVS_HIP(hipStreamWaitEvent(sd->s, sd->fork[nfork & 3], 0));
+    return SVS_OK;
+  };
+  auto forked = [&]() -> int {               // marks the end of this layer's side work
+    if (sd) SVS_HIP(hipEventRecord(sd->done[nfork & 3], sd->s));
+    ++nfork;
+    return SVS_OK;
+  };
+  auto join = [&]() -> int {                 // `stream` waits for all side work of this call
+    if (sd && nfork > 0) SVS_HIP(hipStreamWaitEvent(stream, sd->done[(nfork - 1) & 3], 0));
+    return SVS_OK;
+  };
   if (parts & 1) {
   // deconv6 (model.py:109,198): dw, db, dx -> dcat[1]
   const long half1 = g.P[1] * 16;     // level 1 is planar (cat_half)
-  if ((rc = svs_wgrad_c1_run(t.cat[1], 16, B, g.h[1], g.w[1], 32, t.d_logit, g.h[0], g.w[0], G(44), t.scratch, t.scratch_bytes, stream,
+  if ((rc = fork())) return rc;
+  if ((rc = svs_wgrad_c1_run(t.cat[1], 16, B, g.h[1], g.w[1], 32, t.d_logit, g.h[0], g.w[0], G(44), wscratch, wscratch_bytes, wstream,
                              "deconv6 bwd_weight", half1))) return rc;
+  if ((rc = forked())) return rc;
   if ((rc = svs_sum_run(t.d_logit, g.P[0], G(45), t.scratch, t.scratch_bytes, stream))) return rc;
   if ((rc = svs_conv_c1_run(t.d_logit, B, g.h[0], g.w[0], v.w[11], nullptr, nullptr, nullptr, 0.f, t.dcat[1], 16, 32, 0, stream,
                             "deconv6 bwd_data", half1))) return rc;
@@ -494,18 +559,24 @@ static int train_backward_impl(const ParamView& v, float* grads, const float* mi
     const int lin = 6 - j, lout = 5 - j, l = 6 + j, N = DEC_N[j], C = DEC_C[j];
     const float* x = (j == 0) ? t.c6 : t.cat[lin];
     const View dyv = cat_half(t.dcat, g, lout, 0);
+    float* const d_raw = next_draw();
+    SVS_REQUIRE(d_raw, "svs_unet_train_backward: hipStreamWaitEvent failed");
     rc = svs_bn_bwd_run(dyv.p, dyv.ld, t.raw_d[j], N, g.P[lout], N, (long)g.h[lout] * g.w[lout], v.gamma[l], v.beta[l],
-                        t.mean[l], t.invstd[l], 0.f, drop ? drop + drop_off[j] : nullptr, t.d_raw, G(24 + 4 * j + 2), G(24 + 4 * j + 3),
+                        t.mean[l], t.invstd[l], 0.f, drop ? drop + drop_off[j] : nullptr, d_raw, G(24 + 4 * j + 2), G(24 + 4 * j + 3),
                         G(24 + 4 * j + 1), t.bnws, t.bnws_bytes, stream, unfused ? nullptr : t.dbias_part[l], &sums);   // + bias gradient (sum of d_raw)
     if (rc) return rc;
-    if ((rc = svs_dec_block_bwd_weight(x, C, B, g.h[lin], g.w[lin], C, t.d_raw, N, g.h[lout], g.w[lout], N, G(24 + 4 * j), nullptr,
-                                       t.scratch, t.scratch_bytes, stream))) return rc;
+    if ((rc = fork())) return rc;
+    if ((rc = svs_dec_block_bwd_weight(x, C, B, g.h[lin], g.w[lin], C, d_raw, N, g.h[lout], g.w[lout], N, G(24 + 4 * j), nullptr,
+                                       wscratch, wscratch_bytes, wstream))) return rc;
+    if ((rc = forked())) return rc;
     float* dx = (j == 0) ? t.dc6 : t.dcat[lin];
-    if ((rc = svs_dec_block_bwd_data(t.d_raw, N, B, g.h[lout], g.w[lout], N, t.wbwd[l], dx, C, g.h[lin], g.w[lin], C, 0,
+    if ((rc = svs_dec_block_bwd_data(d_raw, N, B, g.h[lout], g.w[lout], N, t.wbwd[l], dx, C, g.h[lin], g.w[lin], C, 0,
                                      t.scratch, t.scratch_bytes, stream))) return rc;
   }
   if ((rc = svs_channel_sum_finalize_multi_run(sums, stream))) return rc;    // the five decoder bias gradients
   sums.njobs = 0;
+  if ((rc = join())) return rc;
+  nfork = 0;
   }
   if (!(parts & 2)) return SVS_OK;
   // encoders 6..1
@@ -513,22 +584,27 @@ static int train_backward_impl(const ParamView& v, float* grads, const float* mi
     const int l = k - 1, N = CH[k], C = CH[k - 1];
     const View dyv = (k == 6) ? View{t.dc6, 512} : cat_half(t.dcat, g, k, 1);
     const float* dy = dyv.p; const long lddy = dyv.ld;
+    float* const d_raw = next_draw();
+    SVS_REQUIRE(d_raw, "svs_unet_train_backward: hipStreamWaitEvent failed");
     rc = svs_bn_bwd_run(dy, lddy, t.raw_e[k], N, g.P[k], N, (long)g.h[k] * g.w[k], v.gamma[l], v.beta[l], t.mean[l], t.invstd[l],
-                        LEAKY, nullptr, t.d_raw, G(4 * l + 2), G(4 * l + 3), G(4 * l + 1), t.bnws, t.bnws_bytes, stream,
+                        LEAKY, nullptr, d_raw, G(4 * l + 2), G(4 * l + 3), G(4 * l + 1), t.bnws, t.bnws_bytes, stream,
                         unfused ? nullptr : t.dbias_part[l], &sums);
     if (rc) return rc;
     const View xi = (k == 1) ? View{const_cast<float*>(mix), 1} : cat_half(t.cat, g, k - 1, 1);
     const float* x = xi.p; const long ldx = xi.ld;
-    if ((rc = svs_enc_block_bwd_weight(t.d_raw, N, B, g.h[k], g.w[k], N, x, ldx, g.h[k - 1], g.w[k - 1], C, G(4 * l), nullptr,
-                                       t.scratch, t.scratch_bytes, stream))) return rc;
+    if ((rc = fork())) return rc;
+    if ((rc = svs_enc_block_bwd_weight(d_raw, N, B, g.h[k], g.w[k], N, x, ldx, g.h[k - 1], g.w[k - 1], C, G(4 * l), nullptr,
+                                       wscratch, wscratch_bytes, wstream))) return rc;
+    if ((rc = forked())) return rc;
     if (k >= 2) {
       // gradient of the skip half of cat[k-1]: add to what decoder (7-k)'s bwd_data left there
       const View dxs = cat_half(t.dcat, g, k - 1, 1);
-      if ((rc = svs_enc_block_bwd_data(t.d_raw, N, B, g.h[k], g.w[k], N, t.wbwd[l], dxs.p, dxs.ld, g.h[k - 1], g.w[k - 1], C, 1,
+      if ((rc = svs_enc_block_bwd_data(d_raw, N, B, g.h[k], g.w[k], N, t.wbwd[l], dxs.p, dxs.ld, g.h[k - 1], g.w[k - 1], C, 1,
                                        t.scratch, t.scratch_bytes, stream))) return rc;
     }
   }
-  return svs_channel_sum_finalize_multi_run(sums, stream);                    // the six encoder bias gradients
+  if ((rc = svs_channel_sum_finalize_multi_run(sums, stream))) return rc;    // the six encoder bias gradients
+  return join();
 }
 
 static int check_train_ws(const char* who, const Geo& g, void* ws, size_t ws_bytes, TrainWs& t) {
