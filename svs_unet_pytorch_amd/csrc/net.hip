@@ -439,6 +439,7 @@ static int train_forward_impl(const ParamView& v, float* bn_buffers, int64_t* nb
   const int B = g.B;
   int rc;
   const int fused_rows = getenv("SVS_TRAIN_UNFUSED") ? 0 : SVS_FUSED_STATS_ROWS;     // A/B switch
+  SideStream* sd = getenv("SVS_TRAIN_ONE_STREAM") ? nullptr : side_stream();          // A/B switch
   // weight packings for this step (weights change every optimiser step)
   {
     SvsPackJobs jobs{};
@@ -451,10 +452,17 @@ static int train_forward_impl(const ParamView& v, float* bn_buffers, int64_t* nb
       add(v.w[6 + j], t.wfwd[6 + j], DEC_N[j], DEC_C[j], 1);        // convT forward: parity packing, one row per output channel
       add(v.w[6 + j], t.wbwd[6 + j], DEC_C[j], DEC_N[j], 0);        // convT bwd-data: (C,N,..) read as (n=C,c=N)
     }
-    if ((rc = svs_pack_all_run(jobs, stream))) return rc;
+    // conv1 reads torch's layout directly, so the packing runs beside it on the side stream (joined before conv2)
+    if (sd) {
+      SVS_HIP(hipEventRecord(sd->fork[0], stream));
+      SVS_HIP(hipStreamWaitEvent(sd->s, sd->fork[0], 0));
+    }
+    if ((rc = svs_pack_all_run(jobs, sd ? sd->s : stream))) return rc;
+    if (sd) SVS_HIP(hipEventRecord(sd->done[0], sd->s));
   }
   // encoder: conv (+bias) -> raw; batch stats; BN + LeakyReLU -> second half of cat[k]
   for (int k = 1; k <= 6; ++k) {
+    if (k == 2 && sd) SVS_HIP(hipStreamWaitEvent(stream, sd->done[0], 0));
     const View xi = (k == 1) ? View{const_cast<float*>(mix), 1} : cat_half(t.cat, g, k - 1, 1);
     const float* x = xi.p; const long ldx = xi.ld;
     const float* wp = (k == 1) ? v.w[0] : t.wfwd[k - 1];
