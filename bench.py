@@ -62,11 +62,35 @@ def gemm_calls(B, mode, H=512, W=128):
     return calls
 
 
+def useful_fraction(kind, dims):
+    """Share of a layer's nominal 2*M*N*K multiply-adds whose input tap lies inside the image (the rest multiply the
+    zero padding).  Nominal FLOPs are what SURVEY.md 8(d) counts; the `..., true>` kernels skip K-tiles that are all
+    padding, so their MFMA rate is quoted on both bases.  kind: 0 gather, 1 parity, 2 weight gradient."""
+    h, w, c, ho, wo, n = dims
+    def gather(hs, ws, hl, wl):            # 5x5 window, stride 2, pad 2: small grid (hs, ws) over large grid (hl, wl)
+        vh = sum(sum(0 <= 2 * i - 2 + k < hl for k in range(5)) for i in range(hs))
+        vw = sum(sum(0 <= 2 * j - 2 + k < wl for k in range(5)) for j in range(ws))
+        return vh * vw / (25.0 * hs * ws)
+    if kind == 0:
+        return gather(ho, wo, h, w)
+    if kind == 2:
+        return gather(h, w, ho, wo)
+    def axis(n_in, n_out):                 # transposed conv: output o takes taps k with (o + 2 - k) even and in range
+        nominal = valid = 0
+        for o in range(n_out):
+            ks = [k for k in range(5) if (o + 2 - k) % 2 == 0]
+            nominal += len(ks)
+            valid += sum(0 <= (o + 2 - k) // 2 < n_in for k in ks)
+        return valid, nominal
+    (vh, nh), (vw, nw) = axis(h, ho), axis(w, wo)
+    return vh * vw / float(nh * nw)
+
+
 def time_gemm_calls(B, mode, reps=10, only_kernel=None):
     """Each GEMM call of a step, timed with HIP events on torch's current stream (the stream every launch of the
     library is given), attributed to the kernel the planner picks (svs_describe_plan -> the name rocprofv3 shows).
     A call = the GEMM kernel plus, where the planner splits K, its fixed-order slab reduction.
-    Returns [(name, kernel, ksplit, ms, GFLOP)]."""
+    Returns [(name, kernel, ksplit, ms, GFLOP, share of the GFLOP that is not zero padding)]."""
     import ctypes
     L = _lib.lib()
     dev = "cuda"
@@ -101,7 +125,7 @@ def time_gemm_calls(B, mode, reps=10, only_kernel=None):
             run()
         e1.record()
         torch.cuda.synchronize()
-        out.append((name, buf.value.decode(), ks, e0.elapsed_time(e1) / reps, gflop))
+        out.append((name, buf.value.decode(), ks, e0.elapsed_time(e1) / reps, gflop, useful_fraction(kind, (h, w, c, ho, wo, n))))
     return out
 
 
@@ -237,7 +261,7 @@ def main():
             if not args.no_layers:
                 calls = time_gemm_calls(B, args.mode)
                 fam = {}
-                for name, kernel, ks, ms, gf in calls:
+                for name, kernel, ks, ms, gf, _ in calls:
                     e = fam.setdefault(kernel, [0.0, 0.0, 0])
                     e[0] += ms; e[1] += gf; e[2] += 1
                 dom = max(fam, key=lambda k: fam[k][0])
@@ -248,16 +272,21 @@ def main():
                 alone = [c for c in time_gemm_calls(B, args.mode, only_kernel=dom)]
                 os.environ.pop("SVS_SKIP_REDUCE")
                 ms, gf, cnt = sum(c[3] for c in alone), sum(c[4] for c in alone), len(alone)
+                gf_in_image = sum(c[4] * c[5] for c in alone)
                 ach = gf / ms            # GFLOP / ms = TFLOP/s
                 res["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                                    "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(dom),
                                    "launches_per_step": cnt, "avg_launch_ms": round(ms / cnt, 4),
                                    "algorithmic_gflop_per_launch": round(gf / cnt, 3),
+                                   "achieved_in_image": round(gf_in_image / ms, 2),
+                                   "frac_in_image": round(gf_in_image / ms / FP32_MFMA_PEAK_TFLOPS, 4),
                                    "note": "HIP events on the launch stream around each launch of this kernel in one step "
-                                           "(slab reductions excluded); algorithmic FLOPs = 2*M*N*K of the layer"}
+                                           "(slab reductions excluded); algorithmic FLOPs = 2*M*N*K of the layer (SURVEY.md 8d); "
+                                           "*_in_image counts only products whose tap is inside the image -- the share the "
+                                           "padding-skipping kernels cannot avoid executing is between the two"}
                 res["kernels"] = {k: {"calls": v[2], "ms": round(v[0], 4), "tflops": round(v[1] / v[0], 2)} for k, v in fam.items()}
-                res["layers"] = {name: {"kernel": kernel, "ksplit": ks, "ms": round(ms, 4), "tflops": round(gf / ms, 2)}
-                                 for name, kernel, ks, ms, gf in calls}
+                res["layers"] = {name: {"kernel": kernel, "ksplit": ks, "ms": round(ms, 4), "tflops": round(gf / ms, 2),
+                                        "in_image": round(fr, 3)} for name, kernel, ks, ms, gf, fr in calls}
             if not args.no_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline(args.mode)
         print(json.dumps(res), flush=True)

@@ -742,6 +742,18 @@ static int use_parity_window(int mode, int B, int H, int W, int C, int N, long l
   return window;
 }
 
+// narrow levels: batch-innermost rows so that whole taps of an M-tile fall into the padding and are skipped
+static int use_tap_skip(int mode, int B, int C, int Wo, int N, int cfg) {
+  const bool can = N > 32 /* tap-outer K order */ && (C & (C - 1)) == 0 && (cfg == 0 || cfg == 1 || cfg == 4 || cfg == 5);
+  int skip = can && B >= 32 && ((mode == MODE_GATHER) ? Wo : (Wo + 1) / 2) <= 8;
+  if (const char* e = getenv("SVS_CONV_SKIP")) {     // sweeps and tests: 0 = never, 2 = whenever the kernel supports it
+    const int f = atoi(e);
+    skip = (f == 0) ? 0 : (f == 2) ? can : skip;
+  }
+  if (getenv("SVS_CONV_KORDER")) skip = 0;           // (the K-order sweep switch may select tap-inner order)
+  return skip;
+}
+
 // Shared by enc fwd / dec bwd_data (GATHER) and dec fwd / enc bwd_data (PARITY).
 int svs_conv_gemm_run(int mode, const float* x, long ldx, int B, int H, int W, int C, const float* wp,
                       const float* bias, const float* scale, const float* shift, float slope, float* y, long ldy,
@@ -827,14 +839,7 @@ int svs_conv_gemm_run(int mode, const float* x, long ldx, int B, int H, int W, i
     SVS_CHECK_LAUNCH("conv_direct");
     return SVS_OK;
   }
-  // narrow levels: batch-innermost rows so that whole taps of an M-tile fall into the padding and are skipped
-  int skip = B >= 32 && !a.tap_inner && (C & (C - 1)) == 0 && ((mode == MODE_GATHER) ? Wo : (Wo + 1) / 2) <= 8 &&
-             (pl.cfg == 0 || pl.cfg == 1 || pl.cfg == 4 || pl.cfg == 5);
-  if (const char* e = getenv("SVS_CONV_SKIP")) {     // sweeps and tests: 0 = never, 2 = whenever the kernel supports it
-    const int f = atoi(e);
-    const bool can = !a.tap_inner && (C & (C - 1)) == 0 && (pl.cfg == 0 || pl.cfg == 1 || pl.cfg == 4 || pl.cfg == 5);
-    skip = (f == 0) ? 0 : (f == 2) ? can : skip;
-  }
+  const int skip = use_tap_skip(mode, B, C, Wo, N, pl.cfg);
   rc = (mode == MODE_GATHER) ? launch_conv_gemm<MODE_GATHER>(a, pl, stream, skip) : launch_conv_gemm<MODE_PARITY>(a, pl, stream, skip);
   if (rc) return rc;
   if (pl.ksplit > 1 && !getenv("SVS_SKIP_REDUCE")) {      // (the switch lets bench.py time the GEMM kernel alone)
@@ -879,6 +884,7 @@ int svs_conv_gemm_describe(int mode, int B, int H, int W, int C, int Ho, int Wo,
   if (direct) { snprintf(buf, n, "conv_direct_kernel<%d, 4, %d>", mode, N / 16); return 1; }
   static const int wm[10] = {2, 2, 4, 4, 1, 2, 2, 4, 4, 4}, wn[10] = {2, 2, 1, 1, 4, 2, 2, 1, 1, 1};
   const ConvPlan pl = plan_conv(mode, Mmax, N, nkt_min);
-  snprintf(buf, n, "conv_gemm_kernel<%d, %d, %d, %d, %d>", mode, pl.BM, pl.BN, wm[pl.cfg], wn[pl.cfg]);
+  snprintf(buf, n, "conv_gemm_kernel<%d, %d, %d, %d, %d, %s>", mode, pl.BM, pl.BN, wm[pl.cfg], wn[pl.cfg],
+           use_tap_skip(mode, B, C, Wo, N, pl.cfg) ? "true" : "false");
   return pl.ksplit;
 }

@@ -308,6 +308,15 @@ static WgradPlan plan_wgrad(int B, int Hs, int Ws, int Cs, int Cl) {
   return pl;
 }
 
+// deep levels: batch-innermost pixels, K-tiles whose taps are all in the padding are skipped (wgrad_gemm_kernel)
+static int use_wgrad_skip(int B, int Hs, int Ws, int Cl, long lds, int cfg) {
+  const bool can_skip = B >= 16 && (B & (B - 1)) == 0 && (Ws & (Ws - 1)) == 0 && cfg == 0 && Cl >= 32 &&
+                        (long)B * Hs * Ws * lds * 4 < (1L << 31);
+  int skip = can_skip && Ws <= 8;
+  if (const char* e = getenv("SVS_WGRAD_SKIP")) { const int f = atoi(e); skip = (f == 0) ? 0 : (f == 2) ? can_skip : skip; }   // sweeps, tests
+  return skip;
+}
+
 #define WG_GROUPS 8      // slabs are pre-summed in WG_GROUPS parallel groups when there are many of them
 
 size_t svs_wgrad_gemm_workspace(int B, int Hs, int Ws, int Cs, int Cl) {
@@ -338,11 +347,7 @@ int svs_wgrad_gemm_run(const float* s, long lds, int B, int Hs, int Ws, int Cs, 
   SVS_REQUIRE((long)B * Hl * Wl * ldl * 4 < (1L << 31) && (long)(pl.pps + 16) * lds * 4 < (1L << 31),
               "%s: operand views need 64-bit offsets; split the batch", who);
   dim3 grid((unsigned)(Cs / pl.BM), (unsigned)((25 * Cl + pl.BN - 1) / pl.BN), (unsigned)pl.ksplit);
-  // deep levels: batch-innermost pixels, K-tiles whose taps are all in the padding are skipped (wgrad_gemm_kernel)
-  const bool can_skip = B >= 16 && (B & (B - 1)) == 0 && a.ws_shift >= 0 && pl.cfg == 0 && Cl >= 32 &&
-                        (long)B * Hs * Ws * lds * 4 < (1L << 31);
-  int skip = can_skip && Ws <= 8;
-  if (const char* e = getenv("SVS_WGRAD_SKIP")) { const int f = atoi(e); skip = (f == 0) ? 0 : (f == 2) ? can_skip : skip; }   // sweeps, tests
+  const int skip = use_wgrad_skip(B, Hs, Ws, Cl, lds, pl.cfg);
   if (skip) {
     a.b_shift = log2_or_neg(B);
     hipLaunchKernelGGL((wgrad_gemm_kernel<128, 128, 2, 2, true>), grid, dim3(256), 0, stream, a);
@@ -372,6 +377,7 @@ int svs_wgrad_gemm_run(const float* s, long lds, int B, int Hs, int Ws, int Cs, 
 
 int svs_wgrad_gemm_describe(int B, int Hs, int Ws, int Cs, int Cl, char* buf, size_t n) {
   const WgradPlan pl = plan_wgrad(B, Hs, Ws, Cs, Cl);
-  snprintf(buf, n, "wgrad_gemm_kernel<%d, %d, %d, %d>", pl.BM, pl.BN, pl.cfg == 0 ? 2 : 1, pl.cfg == 0 ? 2 : 4);
+  snprintf(buf, n, "wgrad_gemm_kernel<%d, %d, %d, %d, %s>", pl.BM, pl.BN, pl.cfg == 0 ? 2 : 1, pl.cfg == 0 ? 2 : 4,
+           use_wgrad_skip(B, Hs, Ws, Cl, Cs, pl.cfg) ? "true" : "false");
   return pl.ksplit;
 }
