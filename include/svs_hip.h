@@ -201,13 +201,20 @@ int svs_unet_train_backward(const float* params, float* grads, const float* mix,
                             void* ws, size_t ws_bytes, hipStream_t stream);
 /* Split form for overlapping the data-parallel gradient exchange with the backward pass: forward + loss, then
  * backward part 0 (decoder half: gradients of parameter tensors 24..45, i.e. grads[svs_unet_param_offset(24)..))
- * and part 1 (encoder half: tensors 0..23).  The caller starts the all-reduce of the decoder half on a second
- * stream as soon as part 0 is enqueued.  Same results as svs_unet_train_fwd_bwd. */
+ * and part 1 (encoder half: tensors 0..23), or the encoder in two pieces: part 2 (the conv6 block, tensors 20..23 --
+ * 13 of the encoder's 17.5 MB) then part 3 (tensors 0..19).  The caller starts the all-reduce of a piece on a second
+ * stream as soon as the part is enqueued.  Same results as svs_unet_train_fwd_bwd.
+ * Weight gradients are computed on a library-owned side stream.  The call that ends the pass (part 1 or 3) makes
+ * `stream` wait for all of them; after an earlier part, svs_unet_train_bwd_sync(s) makes stream `s` (the one the
+ * exchange is issued from) wait for the side-stream work enqueued so far WITHOUT stalling the backward's own stream
+ * (`s` must also wait for `stream` itself, e.g. with an event).  The parts of one pass must be issued in order from one
+ * host thread; one training pass per device at a time. */
 int svs_unet_train_fwd_loss(const float* params, float* bn_buffers, int64_t* num_batches_tracked, const float* mix,
                             const float* voc, const float* drop, int B, int H, int W, float loss_scale,
                             float* mask /*nullable*/, float* loss, void* ws, size_t ws_bytes, hipStream_t stream);
 int svs_unet_train_bwd_part(const float* params, float* grads, const float* mix, const float* drop, int B, int H, int W,
                             int part, void* ws, size_t ws_bytes, hipStream_t stream);
+int svs_unet_train_bwd_sync(hipStream_t consumer);
 int64_t svs_unet_ws_offset(const char* name, int B, int H, int W, int training);  /* bytes, <0 unknown */
 
 /* ---------------------------------------------------------------------------------------------

@@ -68,6 +68,7 @@ _SIGS = {
     "svs_unet_train_backward": (I, [P, P, P, P, P, P, I, I, I, P, Z, P]),
     "svs_unet_train_fwd_loss": (I, [P, P, P, P, P, P, I, I, I, F, P, P, P, Z, P]),
     "svs_unet_train_bwd_part": (I, [P, P, P, P, I, I, I, I, P, Z, P]),
+    "svs_unet_train_bwd_sync": (I, [P]),
     "svs_unet_ws_offset": (L, [C.c_char_p, I, I, I, I]),
     "svs_stft_frames": (I, [L, I]),
     "svs_stft_fwd": (I, [P, L, I, I, P, P, P]),

@@ -381,7 +381,7 @@ static TrainWs train_layout(const Geo& g, void* ws) {
 // machine while the main stream is in the bandwidth-bound BatchNorm passes and launch gaps, and its small reduction
 // kernels hide under the main stream's GEMMs.  Fork / join are events; d_raw is double-buffered so that the side
 // stream may trail the main one by a layer.  Results do not depend on the interleaving (no atomics anywhere).
-struct SideStream { hipStream_t s; hipEvent_t fork[4], done[4]; };
+struct SideStream { hipStream_t s; hipEvent_t fork[4], done[4], sync; int nfork; };   // nfork: forks of the current backward pass
 static SideStream* g_side[64] = {};
 static std::mutex g_side_mutex;
 static SideStream* side_stream() {
@@ -391,6 +391,7 @@ static SideStream* side_stream() {
   if (!g_side[dev]) {
     SideStream* sd = new SideStream();
     bool ok = hipStreamCreateWithFlags(&sd->s, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&sd->sync, hipEventDisableTiming) == hipSuccess;
     for (int i = 0; i < 4 && ok; ++i)
       ok = hipEventCreateWithFlags(&sd->fork[i], hipEventDisableTiming) == hipSuccess &&
            hipEventCreateWithFlags(&sd->done[i], hipEventDisableTiming) == hipSuccess;
@@ -518,7 +519,7 @@ static int train_forward_impl(const ParamView& v, float* bn_buffers, int64_t* nb
 //        bit 1 = encoder half (conv6..conv1: tensors 0..23).  A data-parallel caller runs them as two calls and
 //        all-reduces the decoder half of the flat gradient buffer while the encoder half is still being computed.
 static int train_backward_impl(const ParamView& v, float* grads, const float* mix, const float* drop, const Geo& g,
-                               const TrainWs& t, hipStream_t stream, int parts = 3) {
+                               const TrainWs& t, hipStream_t stream, int parts = 7) {
   const int B = g.B;
   int rc;
   auto G = [&](int idx) { return grads + svs_unet_param_offset(idx); };
@@ -529,7 +530,11 @@ static int train_backward_impl(const ParamView& v, float* grads, const float* mi
   float* const wscratch = sd ? t.scratch2 : t.scratch;
   const size_t wscratch_bytes = sd ? t.scratch2_bytes : t.scratch_bytes;
   float* const draw[2] = {t.d_raw, sd ? t.d_raw2 : t.d_raw};
-  int nfork = 0;                             // forks so far in this call; fork n uses event slot n & 3 and d_raw buffer n & 1
+  // forks so far in this backward pass (kept in the SideStream across the calls of a split pass, which must come in
+  // order on one host thread); fork n uses event slot n & 3 and d_raw buffer n & 1
+  int nfork_local = 0;
+  int& nfork = sd ? sd->nfork : nfork_local;
+  if (parts & 1) nfork = 0;
   // d_raw buffer of the next layer: the weight gradient that read it two layers ago must have finished
   auto next_draw = [&]() -> float* {
     if (sd && nfork >= 2 && hipStreamWaitEvent(stream, sd->done[(nfork - 2) & 3], 0) != hipSuccess) return nullptr;
@@ -583,12 +588,11 @@ static int train_backward_impl(const ParamView& v, float* grads, const float* mi
   }
   if ((rc = svs_channel_sum_finalize_multi_run(sums, stream))) return rc;    // the five decoder bias gradients
   sums.njobs = 0;
-  if ((rc = join())) return rc;
-  nfork = 0;
   }
-  if (!(parts & 2)) return SVS_OK;
-  // encoders 6..1
+  if (!(parts & 6)) return SVS_OK;
+  // encoders 6..1 (bit 2: block 6, whose 13 MB of gradients are most of the encoder's; bit 4: blocks 5..1)
   for (int k = 6; k >= 1; --k) {
+    if (!(parts & (k == 6 ? 2 : 4))) continue;
     const int l = k - 1, N = CH[k], C = CH[k - 1];
     const View dyv = (k == 6) ? View{t.dc6, 512} : cat_half(t.dcat, g, k, 1);
     const float* dy = dyv.p; const long lddy = dyv.ld;
@@ -611,8 +615,18 @@ static int train_backward_impl(const ParamView& v, float* grads, const float* mi
                                        t.scratch, t.scratch_bytes, stream))) return rc;
     }
   }
-  if ((rc = svs_channel_sum_finalize_multi_run(sums, stream))) return rc;    // the six encoder bias gradients
-  return join();
+  if ((rc = svs_channel_sum_finalize_multi_run(sums, stream))) return rc;    // the encoder bias gradients of this call
+  // `stream` is joined with the side stream only by the call that ends the pass (block 1 included); after an earlier
+  // part of a split pass the caller uses svs_unet_train_bwd_sync() on the stream that consumes that part's gradients
+  return (parts & 4) ? join() : SVS_OK;
+}
+
+extern "C" int svs_unet_train_bwd_sync(hipStream_t consumer) {
+  SideStream* sd = getenv("SVS_TRAIN_ONE_STREAM") ? nullptr : side_stream();
+  if (!sd) return SVS_OK;
+  SVS_HIP(hipEventRecord(sd->sync, sd->s));
+  SVS_HIP(hipStreamWaitEvent(consumer, sd->sync, 0));
+  return SVS_OK;
 }
 
 static int check_train_ws(const char* who, const Geo& g, void* ws, size_t ws_bytes, TrainWs& t) {
@@ -684,7 +698,8 @@ extern "C" int svs_unet_train_bwd_part(const float* params, float* grads, const 
   Geo g; TrainWs t;
   int rc = make_geo(B, H, W, g);
   if (rc) return rc;
-  SVS_REQUIRE(params && grads && mix && (part == 0 || part == 1), "svs_unet_train_bwd_part: bad arguments");
+  SVS_REQUIRE(params && grads && mix && part >= 0 && part <= 3, "svs_unet_train_bwd_part: bad arguments");
   if ((rc = check_train_ws("svs_unet_train_bwd_part", g, ws, ws_bytes, t))) return rc;
-  return train_backward_impl(view_params(params), grads, mix, drop, g, t, stream, part == 0 ? 1 : 2);
+  static const int bits[4] = {1, 2 | 4, 2, 4};     // decoder | whole encoder | conv6 block | conv5..conv1 blocks
+  return train_backward_impl(view_params(params), grads, mix, drop, g, t, stream, bits[part]);
 }

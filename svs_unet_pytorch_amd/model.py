@@ -191,6 +191,7 @@ class UNet(nn.Module):
         self._anchor = None
         self._injected_masks = None
         self.dropout_seed = 4242
+        self._xstream = None            # stream the overlapped gradient exchange is issued from
         self.dropout_step = 0
         self.rank = 0
         self._flatten()
@@ -405,9 +406,9 @@ class UNet(nn.Module):
         return loss[0]
 
     def fwd_bwd_overlapped(self, mix, voc, loss_scale, grad_sync):
-        """Same result as fwd_bwd, as three library calls so that the gradient exchange overlaps the backward:
+        """Same result as fwd_bwd, as four library calls so that the gradient exchange overlaps the backward:
         forward + loss; backward of the decoder half (its gradients occupy the tail of the flat buffer) followed
-        at once by an asynchronous all-reduce of that tail; backward of the encoder half; all-reduce of the head.
+        at once by an asynchronous all-reduce of that tail; the conv6 block and its all-reduce; conv5..conv1 and theirs.
         Returns (loss, [work handles])."""
         mix, voc = self._check_input(mix), self._check_input(voc)
         B, _, H, W = mix.shape
@@ -422,11 +423,22 @@ class UNet(nn.Module):
                                         B, H, W, float(loss_scale), None, ptr(loss), ptr(ws), ws.numel(), _lib.stream_ptr()),
               "svs_unet_train_fwd_loss")
         split = int(L.svs_unet_param_offset(24))           # first decoder tensor (deconv1.weight)
+        c6 = int(L.svs_unet_param_offset(20))              # conv6.weight: the conv6 block is 13 of the encoder's 17.5 MB
         handles = []
-        for part, sl in ((0, self._gflat[split:]), (1, self._gflat[:split])):
+        # decoder -> conv6 block -> conv5..conv1: only the last, 4.4 MB piece is exchanged after the backward has ended
+        main = torch.cuda.current_stream(mix.device)
+        if self._xstream is None:
+            self._xstream = torch.cuda.Stream(device=mix.device)
+        xs = self._xstream
+        for part, sl in ((0, self._gflat[split:]), (2, self._gflat[c6:split]), (3, self._gflat[:c6])):
             check(L.svs_unet_train_bwd_part(ptr(self._flat), ptr(self._gflat), ptr(mix), ptr(self._drop), B, H, W, part, ptr(ws),
                                             ws.numel(), _lib.stream_ptr()), "svs_unet_train_bwd_part")
-            handles.append(grad_sync.reduce_async(sl))
+            # the exchange is issued from a stream that waits for this part on BOTH compute streams (the backward's own and
+            # the library's weight-gradient stream); the backward itself goes on without waiting for either
+            xs.wait_stream(main)
+            check(L.svs_unet_train_bwd_sync(xs.cuda_stream), "svs_unet_train_bwd_sync")
+            with torch.cuda.stream(xs):
+                handles.append(grad_sync.reduce_async(sl))
         self._grads_clean = False
         return loss[0], handles
 

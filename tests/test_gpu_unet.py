@@ -251,8 +251,9 @@ def test_train_step_learns_and_checkpoint_roundtrip(tmp_path, report):
 
 
 def test_split_backward_equals_fused(report):
-    """The overlapped data-parallel path (forward+loss, decoder-half backward, encoder-half backward as three
-    library calls with the exchange hook in between) must produce the fused call's gradients bit for bit."""
+    """The overlapped data-parallel path (forward+loss, then the backward of the decoder blocks, of the conv6 block and
+    of conv5..conv1 as separate library calls with the exchange hook after each) must produce the fused call's
+    gradients bit for bit; the two-piece form of the ABI (part 1 = whole encoder) is checked as well."""
     B = 3
     mix_np, voc_np = synth.tiles(B, first_tile=700)
     mix, voc = torch.from_numpy(mix_np).to(DEV), torch.from_numpy(voc_np).to(DEV)
@@ -278,11 +279,21 @@ def test_split_backward_equals_fused(report):
     la = a.fwd_bwd(mix, voc, loss_scale=166.66)
     sync = FakeSync()
     lb, handles = b.fwd_bwd_overlapped(mix, voc, 166.66, sync)
-    assert la.item() == lb.item() and len(handles) == 2
+    assert la.item() == lb.item() and len(handles) == 3
     assert torch.equal(a._gflat, b._gflat)
-    split = int(_lib.lib().svs_unet_param_offset(24))
-    assert sync.calls == [(b._gflat.data_ptr() + 4 * split, b._n_params - split), (b._gflat.data_ptr(), split)]
+    split, c6 = int(_lib.lib().svs_unet_param_offset(24)), int(_lib.lib().svs_unet_param_offset(20))
+    assert sync.calls == [(b._gflat.data_ptr() + 4 * split, b._n_params - split),       # decoder blocks
+                          (b._gflat.data_ptr() + 4 * c6, split - c6),                     # conv6 block
+                          (b._gflat.data_ptr(), c6)]                                      # conv1..conv5 blocks
     assert torch.equal(a._bn_flat, b._bn_flat)
+    # two-piece form through the ABI on b's state: decoder, then the whole encoder
+    L, S = _lib.lib(), _lib.stream_ptr
+    ws = b._workspace("train", B, 512, 128)
+    g2 = torch.zeros_like(b._gflat)
+    for part in (0, 1):
+        _lib.check(L.svs_unet_train_bwd_part(b._flat.data_ptr(), g2.data_ptr(), mix.data_ptr(), b._drop.data_ptr(), B, 512, 128, part,
+                                             ws.data_ptr(), ws.numel(), S()), "svs_unet_train_bwd_part")
+    assert torch.equal(g2, a._gflat)
     # and a whole step through train_step with the hook
     l2 = b.train_step(mix, voc, loss_scale=166.66, grad_sync=sync)
     l1 = a.train_step(mix, voc, loss_scale=166.66)
