@@ -129,6 +129,10 @@ def test_inference_tiling_golden(golden, report):
             assert report(f"inference {key} vs reference inference.py", np.abs(got - g[key]).max(), 1e-4)
 
 
+def relerr(got, want):
+    return ((got.double() - want.double()).abs().max() / want.double().abs().max().clamp_min(1e-30)).item()
+
+
 def _grads_by_name(model):
     return {n: p.grad.detach().cpu().double() for n, p in model.named_parameters()}
 
@@ -227,6 +231,54 @@ def test_train_vs_oracle_live_and_autograd_path(report):
     twice = _grads_by_name(model2)
     n = "deconv3.weight"
     assert report("gradient accumulation", (twice[n] - 2 * auto[n]).norm().item() / auto[n].norm().item(), 1e-3)
+
+
+def test_production_kernels_at_batch_32(report, monkeypatch):
+    """The kernels the planner only picks at production batch sizes -- LDS-window parity kernels, batch-innermost row
+    order with padding-tap skipping (conv and weight-gradient GEMMs), BatchNorm partials from the split-K epilogue,
+    batched bias-gradient reduction, weight gradients on the side stream -- in one whole train step at B = 32:
+    loss against the fp32 CPU oracle, and every gradient / BatchNorm buffer against the same step with all of those
+    paths switched off (plain GEMM kernels, one stream, one launch per reduction)."""
+    B = 32
+    mix_np, voc_np = synth.tiles(B, first_tile=1300)
+    mix, voc = torch.from_numpy(mix_np).to(DEV), torch.from_numpy(voc_np).to(DEV)
+    masks = [torch.from_numpy(m) for m in synth.dropout_masks(B, seed=21, step=0)]
+    buf = ctypes.create_string_buffer(128)
+    L = _lib.lib()
+    L.svs_describe_plan(1, B, 128, 32, 64, 256, 64, 16, buf, 128)            # deconv5 forward
+    assert buf.value.decode().startswith("parity_window_kernel"), buf.value
+    L.svs_describe_plan(0, B, 16, 4, 256, 8, 2, 512, buf, 128)               # conv6 forward
+    assert buf.value.decode().endswith("true>"), buf.value
+    L.svs_describe_plan(2, B, 8, 2, 512, 0, 0, 256, buf, 128)                # conv6 weight gradient
+    assert buf.value.decode().endswith("true>"), buf.value
+
+    def run():
+        m = make_model(trained_stats=False).train()
+        m.set_dropout_masks(masks)
+        m.optim.zero_grad()
+        loss = m.fwd_bwd(mix, voc, loss_scale=166.66)
+        torch.cuda.synchronize()
+        return loss.item(), m._gflat.clone(), m._bn_flat.clone(), _grads_by_name(m)
+
+    loss_fast, g_fast, bn_fast, named = run()
+    for k, v in (("SVS_CONV_SKIP", "0"), ("SVS_WGRAD_SKIP", "0"), ("SVS_CONV_WINDOW", "0"), ("SVS_TRAIN_ONE_STREAM", "1"),
+                 ("SVS_TRAIN_UNFUSED", "1")):
+        monkeypatch.setenv(k, v)
+    L.svs_describe_plan(0, B, 16, 4, 256, 8, 2, 512, buf, 128)
+    assert buf.value.decode().endswith("false>"), buf.value
+    loss_plain, g_plain, bn_plain, named_plain = run()
+    assert report("B32 loss: production vs plain kernels", abs(loss_fast - loss_plain) / loss_plain, 1e-6)
+    assert report("B32 BatchNorm buffers: production vs plain kernels", relerr(bn_fast, bn_plain), 1e-6)
+    for n in named:
+        if n.endswith(".bias") and n != "deconv6.bias":
+            continue                                           # bias in front of a BatchNorm: rounding noise around 0
+        d = (named[n] - named_plain[n]).norm().item() / max(named_plain[n].norm().item(), 1e-12)
+        assert report(f"B32 grad {n}: production vs plain kernels", d, 2e-4)
+    st = uo.to_torch_state(synth.closed_form_state(trained_stats=False))
+    opt = uo.new_adam_state(st)
+    lo, _ = uo.train_step(st, opt, torch.from_numpy(mix_np), torch.from_numpy(voc_np), dropout_masks=masks, loss_scale=166.66,
+                          apply_update=False)
+    assert report("B32 loss vs fp32 CPU oracle", abs(loss_fast - lo) / lo, 1e-5)
 
 
 def test_train_step_learns_and_checkpoint_roundtrip(tmp_path, report):
