@@ -9,7 +9,7 @@
 // partial layout: ws[blk][2][C]
 // ------------------------------------------------------------------------------------------------
 static inline int red_blocks(long P, int C) {
-  long nb = (P * C) / 16384;
+  long nb = (P * C) / 4096;              // 16 float4 per thread: the small (deep-level) tensors are latency-bound, not bandwidth-bound
   if (nb > 1024) nb = 1024;
   if (nb < 1) nb = 1;
   return (int)nb;

@@ -657,19 +657,23 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
 // ---- host side ---------------------------------------------------------------------------------
 struct ConvPlan { int cfg; int BM, BN; int ksplit; long mtiles; int grid_y; };
 
-static ConvPlan plan_conv(int mode, long Mmax, int N, int nkt_min) {
+static ConvPlan plan_conv(int mode, long Mmax, int N, int nkt_min, bool narrow = false) {
   ConvPlan pl{};
   if (N % 128 == 0) {
     if (Mmax <= 96) { pl.cfg = 4; pl.BM = 32; pl.BN = 128; }
     else { pl.cfg = 0; pl.BM = 128; pl.BN = 128; }
   } else if (N == 64) {
-    if (Mmax <= 512) { pl.cfg = 5; pl.BM = 64; pl.BN = 64; }
+    if (Mmax <= 512 || nkt_min <= 25) { pl.cfg = 5; pl.BM = 64; pl.BN = 64; }      // (16 input channels: deconv5 backward-data, -9 % in the sweep)
     else { pl.cfg = 1; pl.BM = 128; pl.BN = 64; }
   } else if (N == 32) { pl.cfg = 2; pl.BM = 256; pl.BN = 32; }
   else { pl.cfg = 3; pl.BM = 256; pl.BN = 16; }
   // Parity blocks differ in length (9/6/6/4 taps): many small tiles balance better than few big ones
   // (tools/gemm_sweep.py, B=64: 64x64 tiles beat 128-wide ones by 10-20% whenever M per parity > 1024).
   if (mode == MODE_PARITY && N % 64 == 0 && Mmax > 1024) { pl.cfg = 5; pl.BM = 64; pl.BN = 64; }
+  // Narrow (deep) levels with batch-innermost rows: a 64-row tile is one pixel position of 64 images, so the padding
+  // skip is exact per position, and 4x the tiles need a quarter of the K-splits (same-device sweep at B=64: 64x64
+  // beats 128x128 on every such layer, by 20 % on the 8x2 parity layers).
+  if (narrow && N % 64 == 0) { pl.cfg = 5; pl.BM = 64; pl.BN = 64; }
   if (const char* e = getenv("SVS_CONV_CFG")) {      // sweeps only
     static const int bm[6] = {128, 128, 256, 256, 32, 64}, bn[6] = {128, 64, 32, 16, 128, 64};
     const int c = atoi(e);
@@ -742,6 +746,11 @@ static int use_parity_window(int mode, int B, int H, int W, int C, int N, long l
   return window;
 }
 
+static bool narrow_level(int mode, int B, int C, int Wo, int N) {
+  if (getenv("SVS_CONV_SKIP") || getenv("SVS_CONV_KORDER")) return false;          // sweeps and tests keep the generic tiles
+  return N > 32 && (C & (C - 1)) == 0 && B >= 32 && ((mode == MODE_GATHER) ? Wo : (Wo + 1) / 2) <= 8;
+}
+
 // narrow levels: batch-innermost rows so that whole taps of an M-tile fall into the padding and are skipped
 static int use_tap_skip(int mode, int B, int C, int Wo, int N, int cfg) {
   const bool can = N > 32 /* tap-outer K order */ && (C & (C - 1)) == 0 && (cfg == 0 || cfg == 1 || cfg == 4 || cfg == 5);
@@ -777,7 +786,7 @@ int svs_conv_gemm_run(int mode, const float* x, long ldx, int B, int H, int W, i
   // operands are addressed with 32-bit byte offsets (buffer loads): each view must stay below 2 GiB
   SVS_REQUIRE(((long)B * H * W * ldx + 4L * (W + 2) * ldx) * 4 < (1L << 31) && (long)N * C * 25 * 4 < (1L << 31),
               "%s: input view of %ld bytes needs 64-bit offsets; split the batch", who, (long)B * H * W * ldx * 4);
-  ConvPlan pl = plan_conv(mode, Mmax, N, nkt_min);
+  ConvPlan pl = plan_conv(mode, Mmax, N, nkt_min, narrow_level(mode, B, C, Wo, N));
   ConvGemmArgs a{};
   a.x = x; a.ldx = ldx; a.B = B; a.H = H; a.W = W; a.C = C; a.wp = wp;
   a.bias = bias; a.scale = scale; a.shift = shift; a.slope = slope;
@@ -863,7 +872,7 @@ size_t svs_conv_gemm_workspace(int mode, int B, int H, int W, int C, int Ho, int
   int nkt_min;
   if (mode == MODE_GATHER) { Mmax = (long)B * Ho * Wo; nkt_min = 25 * (C / 16); }
   else { Mmax = (long)B * ((Ho + 1) / 2) * ((Wo + 1) / 2); nkt_min = 4 * (C / 16); }
-  ConvPlan pl = plan_conv(mode, Mmax, N, nkt_min);
+  ConvPlan pl = plan_conv(mode, Mmax, N, nkt_min, narrow_level(mode, B, C, Wo, N));
   if (pl.ksplit <= 1) return 0;
   return (size_t)pl.ksplit * B * Ho * Wo * N * sizeof(float);
 }
@@ -883,7 +892,7 @@ int svs_conv_gemm_describe(int mode, int B, int H, int W, int C, int Ho, int Wo,
   if (use_parity_window(mode, B, H, W, C, N, ldx)) { snprintf(buf, n, "parity_window_kernel<%d, %d, %d>", C, C == 32 ? 32 : 64, N / 16); return 1; }
   if (direct) { snprintf(buf, n, "conv_direct_kernel<%d, 4, %d>", mode, N / 16); return 1; }
   static const int wm[10] = {2, 2, 4, 4, 1, 2, 2, 4, 4, 4}, wn[10] = {2, 2, 1, 1, 4, 2, 2, 1, 1, 1};
-  const ConvPlan pl = plan_conv(mode, Mmax, N, nkt_min);
+  const ConvPlan pl = plan_conv(mode, Mmax, N, nkt_min, narrow_level(mode, B, C, Wo, N));
   snprintf(buf, n, "conv_gemm_kernel<%d, %d, %d, %d, %d, %s>", mode, pl.BM, pl.BN, wm[pl.cfg], wn[pl.cfg],
            use_tap_skip(mode, B, C, Wo, N, pl.cfg) ? "true" : "false");
   return pl.ksplit;
