@@ -291,6 +291,15 @@ static WgradPlan plan_wgrad(int B, int Hs, int Ws, int Cs, int Cl) {
   if (Cs % 128 == 0) { pl.cfg = 0; pl.BM = 128; }
   else if (Cs % 64 == 0) { pl.cfg = 1; pl.BM = 64; }
   else { pl.cfg = 2; pl.BM = 32; }
+  // 64-row tiles where the 128-row ones leave too few blocks per K-split (same-device sweep at B=64: the 8x2 level and
+  // the 32-channel windows gain 4-8 %, everything else is neutral or loses)
+  if (pl.cfg == 0 && ((long)B * Hs * Ws <= 1024 || Cl <= 32)) { pl.cfg = 1; pl.BM = 64; }
+  if (const char* e = getenv("SVS_WGRAD_CFG")) {     // sweeps only
+    const int c = atoi(e);
+    if (c == 0 && Cs % 128 == 0) { pl.cfg = 0; pl.BM = 128; }
+    if (c == 1 && Cs % 64 == 0) { pl.cfg = 1; pl.BM = 64; }
+    if (c == 2 && Cs % 32 == 0) { pl.cfg = 2; pl.BM = 32; }
+  }
   pl.BN = 128;
   const long P = (long)B * Hs * Ws;
   const long blocks_mn = (long)(Cs / pl.BM) * ((25L * Cl + pl.BN - 1) / pl.BN);
@@ -310,7 +319,7 @@ static WgradPlan plan_wgrad(int B, int Hs, int Ws, int Cs, int Cl) {
 
 // deep levels: batch-innermost pixels, K-tiles whose taps are all in the padding are skipped (wgrad_gemm_kernel)
 static int use_wgrad_skip(int B, int Hs, int Ws, int Cl, long lds, int cfg) {
-  const bool can_skip = B >= 16 && (B & (B - 1)) == 0 && (Ws & (Ws - 1)) == 0 && cfg == 0 && Cl >= 32 &&
+  const bool can_skip = B >= 16 && (B & (B - 1)) == 0 && (Ws & (Ws - 1)) == 0 &&
                         (long)B * Hs * Ws * lds * 4 < (1L << 31);
   int skip = can_skip && Ws <= 8;
   if (const char* e = getenv("SVS_WGRAD_SKIP")) { const int f = atoi(e); skip = (f == 0) ? 0 : (f == 2) ? can_skip : skip; }   // sweeps, tests
@@ -350,7 +359,9 @@ int svs_wgrad_gemm_run(const float* s, long lds, int B, int Hs, int Ws, int Cs, 
   const int skip = use_wgrad_skip(B, Hs, Ws, Cl, lds, pl.cfg);
   if (skip) {
     a.b_shift = log2_or_neg(B);
-    hipLaunchKernelGGL((wgrad_gemm_kernel<128, 128, 2, 2, true>), grid, dim3(256), 0, stream, a);
+    if (pl.cfg == 0) hipLaunchKernelGGL((wgrad_gemm_kernel<128, 128, 2, 2, true>), grid, dim3(256), 0, stream, a);
+    else if (pl.cfg == 1) hipLaunchKernelGGL((wgrad_gemm_kernel<64, 128, 1, 4, true>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((wgrad_gemm_kernel<32, 128, 1, 4, true>), grid, dim3(256), 0, stream, a);
   } else switch (pl.cfg) {
     case 0: hipLaunchKernelGGL((wgrad_gemm_kernel<128, 128, 2, 2>), grid, dim3(256), 0, stream, a); break;
     case 1: hipLaunchKernelGGL((wgrad_gemm_kernel<64, 128, 1, 4>), grid, dim3(256), 0, stream, a); break;

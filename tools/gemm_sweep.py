@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--only", default="", help="comma-separated substrings of call names to run")
     ap.add_argument("--cfgs", default="", help="comma-separated config ids to try (default all)")
     ap.add_argument("--no-wgrad", action="store_true")
+    ap.add_argument("--no-conv", action="store_true")
+    ap.add_argument("--no-ks", action="store_true", help="skip the K-split sweep of the weight gradients")
     ap.add_argument("--ab", action="store_true", help="A/B an environment switch per call (see --ab-env)")
     ap.add_argument("--ab-env", default="SVS_CONV_KORDER", help="switch toggled by --ab")
     ap.add_argument("--ab-vals", default="0,1", help="comma-separated values of the switch")
@@ -74,7 +76,7 @@ def main():
     only = [t for t in args.only.split(",") if t]
     cfgs = [int(t) for t in args.cfgs.split(",") if t]
     for name, mode, (h, w, C), (ho, wo, N) in calls:
-        if only and not any(t in name for t in only):
+        if args.no_conv or (only and not any(t in name for t in only)):
             continue
         x = torch.rand((B, h, w, C), device=dev) - 0.5
         wp = (torch.rand(N * C * 25, device=dev) - 0.5) * 0.05
@@ -128,6 +130,8 @@ def main():
     for j, (c, n) in enumerate(DEC):
         wg.append((f"deconv{j + 1}.bwd_weight", hw[6 - j], c, hw[5 - j], n))
     for name, (hs, wsz), cs, (hl, wl), cl in wg:
+        if only and not any(t in name for t in only):
+            continue
         s = torch.rand((B, hs, wsz, cs), device=dev) - 0.5
         l = torch.rand((B, hl, wl, cl), device=dev) - 0.5
         dw = torch.empty(cs * cl * 25, device=dev)
@@ -138,7 +142,16 @@ def main():
         _lib.check(run(), name)
         base = timeit(run)
         emit(f"{name:20s} S {hs}x{wsz}x{cs} L {hl}x{wl}x{cl} {gflop:7.2f} GFLOP  default {base * 1e3:8.1f} us {gflop / base:6.1f} TF")
-        for ks in (1, 2, 4, 8, 16, 32, 64, 128, 256):
+        if args.ab:
+            res = []
+            for rnd in range(3):
+                for ko in args.ab_vals.split(","):
+                    os.environ[args.ab_env] = ko
+                    run()
+                    res.append((ko, timeit(run)))
+            os.environ.pop(args.ab_env, None)
+            emit(f"    A/B {args.ab_env}: " + "  ".join(f"={v} {min(t for k, t in res if k == v) * 1e3:7.1f} us" for v in args.ab_vals.split(",")))
+        for ks in (() if args.no_ks else (1, 2, 4, 8, 16, 32, 64, 128, 256)):
             os.environ["SVS_WGRAD_KSPLIT"] = str(ks)
             if run() != 0:
                 continue
