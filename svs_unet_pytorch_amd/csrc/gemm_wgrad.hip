@@ -260,6 +260,120 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(WgradArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// LDS-window weight gradient for the shallow layers (few channels, many pixels: conv2, conv3, deconv4, deconv5).
+// There the GEMM above has M = Cs = 32..128 rows only, so its tiles are small, every windowed pixel is re-staged for
+// each of the 25 taps and K is split 147-256 ways.  Here a block walks a run of S-tiles (4 x 16 pixels of one image):
+// the tile's S pixels (a 16*MT-channel slice) and the (2*4+3) x (2*16+3) window of L they touch (a 16-channel slice)
+// are staged ONCE in LDS, and wave (mt, half) accumulates dw[16 cs of m-tile mt][25 taps x 16 cl] in 25 MFMA
+// accumulators over its share of the tile's pixels -- every operand is a ds_read_b32 at base + compile-time offset
+// (the tap only changes the offset), there is no per-tap global traffic and no address arithmetic in the loop.
+// A block keeps its accumulators across all its tiles and writes one slab per wave-half at the end; the slabs go
+// through the same fixed-order reductions as the GEMM's.
+//   MFMA operands: A[m = cs][k = pixel] = S[pixel][cs] (pixel-major LDS rows, pitch LS: 4 pixels x 16 cs hit 64
+//   different banks), B[k = pixel][n = cl] = L[window pixel of (pixel, tap)][cl] (pitch LL = 24 floats: the four
+//   pixels of a k-step are 2 window columns apart -> offsets 0/48/96/144 floats, again 64 different banks).
+// ------------------------------------------------------------------------------------------------
+struct WgWinArgs {
+  const float* s; long lds; const float* l; long ldl;
+  int B, Hs, Ws, Cs, Hl, Wl, Cl;
+  float* slab;                 // [gridDim.x * (4 / MT)][Cs][25 * Cl]
+  int ntiles, tiles_per_block;
+};
+
+template <int MT>              // 16-row m-tiles per block (one per wave, or per pair of waves when MT = 2)
+__global__ __launch_bounds__(256, 2) void wgrad_window_kernel(WgWinArgs p) {
+  constexpr int TH = 4, TW = 16, KS = 4 / MT, CSB = 16 * MT;
+  constexpr int LS = CSB + 16;                       // 48 / 80 floats
+  constexpr int LH = 2 * TH + 3, LW = 2 * TW + 3, LL = 24;
+  constexpr int NS = TH * TW * (CSB / 4), NL = LH * LW * 4;       // 16-byte pieces to stage
+  constexpr int RS = (NS + 255) / 256, RL = (NL + 255) / 256;
+  constexpr int KSTEPS = TH * TW / 4 / KS;           // k-steps (4 pixels each) per wave and tile
+  constexpr unsigned OOB = 0x80000000u;
+  __shared__ __attribute__((aligned(16))) float Ssm[TH * TW * LS];
+  __shared__ __attribute__((aligned(16))) float Lsm[LH * LW * LL];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int lrow = lane & 15, q = lane >> 4;
+  const int mt = wave % MT, half = wave / MT;
+  const int mchunks = p.Cs / CSB;
+  const int m0 = (blockIdx.y % mchunks) * CSB, cl0 = (blockIdx.y / mchunks) * 16;
+  const int tiles_w = (p.Ws + TW - 1) / TW, tiles_h = (p.Hs + TH - 1) / TH;
+  const int tile_lo = blockIdx.x * p.tiles_per_block;
+  const int tile_hi = min(tile_lo + p.tiles_per_block, p.ntiles);
+
+  f32x4 sreg[RS], lreg[RL];
+  auto fetch = [&](int tile) {                       // global -> registers; outside the image / the tile -> zeros
+    const int tw0 = (tile % tiles_w) * TW, th0 = ((tile / tiles_w) % tiles_h) * TH;
+    const long b = tile / (tiles_w * tiles_h);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.s + b * p.Hs * p.Ws * p.lds), 0, OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void*)(p.l + b * p.Hl * p.Wl * p.ldl), 0, OOB, 0x00020000);
+#pragma unroll
+    for (int r = 0; r < RS; ++r) {
+      const int e = t + 256 * r;
+      const int c4 = e % (CSB / 4), px = e / (CSB / 4);
+      const int sh = th0 + px / TW, sw = tw0 + px % TW;
+      const bool ok = e < NS && sh < p.Hs && sw < p.Ws;
+      const unsigned vo = ok ? (unsigned)(((sh * p.Ws + sw) * (int)p.lds + m0 + c4 * 4) * 4) : OOB;
+      sreg[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)vo, 0, 0));
+    }
+#pragma unroll
+    for (int r = 0; r < RL; ++r) {
+      const int e = t + 256 * r;
+      const int c4 = e & 3, px = e >> 2;
+      const int ih = 2 * th0 - 2 + px / LW, iw = 2 * tw0 - 2 + px % LW;
+      const bool ok = e < NL && (unsigned)ih < (unsigned)p.Hl && (unsigned)iw < (unsigned)p.Wl;
+      const unsigned vo = ok ? (unsigned)(((ih * p.Wl + iw) * (int)p.ldl + cl0 + c4 * 4) * 4) : OOB;
+      lreg[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rl, (int)vo, 0, 0));
+    }
+  };
+  auto stage = [&]() {                               // registers -> LDS
+#pragma unroll
+    for (int r = 0; r < RS; ++r) {
+      const int e = t + 256 * r;
+      if (e < NS) *(f32x4*)(&Ssm[(e / (CSB / 4)) * LS + (e % (CSB / 4)) * 4]) = sreg[r];
+    }
+#pragma unroll
+    for (int r = 0; r < RL; ++r) {
+      const int e = t + 256 * r;
+      if (e < NL) *(f32x4*)(&Lsm[(e >> 2) * LL + (e & 3) * 4]) = lreg[r];
+    }
+  };
+
+  f32x4 acc[25];
+#pragma unroll
+  for (int i = 0; i < 25; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // this wave's k-steps are rows [half * TH / KS, ...) of the tile; lane (lrow, q): pixel column 4 * (kstep % 4) + q
+  const float* abase = &Ssm[(half * (TH / KS) * TW + q) * LS + mt * 16 + lrow];
+  const float* bbase = &Lsm[(half * (TH / KS) * 2 * LW + 2 * q) * LL + lrow];
+
+  if (tile_lo < tile_hi) fetch(tile_lo);
+  for (int tile = tile_lo; tile < tile_hi; ++tile) {
+    __syncthreads();                                 // the previous tile's readers are done
+    stage();
+    __syncthreads();
+    if (tile + 1 < tile_hi) fetch(tile + 1);         // in flight while this tile is multiplied
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      const int sh = ks / 4, sg = ks % 4;            // row within this wave's share, group of 4 pixel columns
+      const float a = abase[(sh * TW + sg * 4) * LS];
+#pragma unroll
+      for (int tap = 0; tap < 25; ++tap) {
+        const int kh = tap / 5, kw = tap % 5;
+        const float bv = bbase[((2 * sh + kh) * LW + 8 * sg + kw) * LL];
+        acc[tap] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc[tap], 0, 0, 0);
+      }
+    }
+  }
+  // acc[tap][r]: row cs = m0 + 16 mt + 4 q + r, column n = tap * Cl + cl0 + lrow
+  const int Ntot = 25 * p.Cl;
+  float* slab = p.slab + ((long)blockIdx.x * KS + half) * p.Cs * Ntot;
+#pragma unroll
+  for (int tap = 0; tap < 25; ++tap)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      slab[(long)(m0 + mt * 16 + 4 * q + r) * Ntot + tap * p.Cl + cl0 + lrow] = acc[tap][r];
+}
+
 // dw[(cs*Cl + cl)*25 + tap] = sum_z slab[z][cs][tap*Cl + cl].  One block per (cs, 64-channel chunk of cl):
 // slabs are read along cl (coalesced), transposed through LDS, and written as one contiguous run of dw.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int ksplit, int Cs, int Cl,
@@ -328,9 +442,52 @@ static int use_wgrad_skip(int B, int Hs, int Ws, int Cl, long lds, int cfg) {
 
 #define WG_GROUPS 8      // slabs are pre-summed in WG_GROUPS parallel groups when there are many of them
 
+// window kernel: which layers, and how many blocks / slabs
+struct WgWinPlan { int use, MT, gy, gx, tpb, ntiles, nslab; };
+static WgWinPlan plan_wgrad_window(int B, int Hs, int Ws, int Cs, int Cl) {
+  WgWinPlan w{};
+  const bool eligible = (Cl == 16 || Cl == 32) && (Cs == 32 || Cs == 64 || Cs == 128);
+  w.ntiles = B * ((Hs + 3) / 4) * ((Ws + 15) / 16);
+  w.use = eligible && w.ntiles >= 1024;
+  if (const char* e = getenv("SVS_WGRAD_WINDOW")) { const int f = atoi(e); w.use = (f == 0) ? 0 : (f == 2) ? eligible : w.use; }   // sweeps, tests
+  if (!w.use) return w;
+  w.MT = (Cs % 64 == 0) ? 4 : 2;
+  w.gy = (Cs / (16 * w.MT)) * (Cl / 16);
+  int gx = 512 / w.gy;                       // two resident blocks per CU
+  if (gx > w.ntiles) gx = w.ntiles;
+  w.tpb = (w.ntiles + gx - 1) / gx;
+  w.gx = (w.ntiles + w.tpb - 1) / w.tpb;
+  w.nslab = w.gx * (4 / w.MT);
+  return w;
+}
+
 size_t svs_wgrad_gemm_workspace(int B, int Hs, int Ws, int Cs, int Cl) {
   WgradPlan pl = plan_wgrad(B, Hs, Ws, Cs, Cl);
-  return (size_t)(pl.ksplit + WG_GROUPS) * Cs * 25 * Cl * sizeof(float);
+  size_t nslab = (size_t)pl.ksplit;
+  // the window kernel's slab count does not depend on the sweep / test switches' current value: take the larger
+  const int tiles = B * ((Hs + 3) / 4) * ((Ws + 15) / 16);
+  if ((Cl == 16 || Cl == 32) && (Cs == 32 || Cs == 64 || Cs == 128)) {
+    const int MT = (Cs % 64 == 0) ? 4 : 2, gy = (Cs / (16 * MT)) * (Cl / 16);
+    size_t gx = (size_t)(512 / gy < tiles ? 512 / gy : tiles);
+    if (gx * (4 / MT) > nslab) nslab = gx * (4 / MT);
+  }
+  return (nslab + WG_GROUPS) * Cs * 25 * Cl * sizeof(float);
+}
+
+// fixed-order sum of nslab slabs [Cs][25*Cl] into torch's (cs, cl, kh, kw) layout; tmp: WG_GROUPS more slabs
+static int wgrad_reduce_run(const float* slabs, int nslab, int Cs, int Cl, float* dw, float* tmp, hipStream_t stream) {
+  const long n = (long)Cs * 25 * Cl;
+  if (nslab > 2 * WG_GROUPS) {     // long serial chains per output element: sum in WG_GROUPS parallel groups first
+    const int per = (nslab + WG_GROUPS - 1) / WG_GROUPS;
+    const int groups = (nslab + per - 1) / per;
+    if (int rc = svs_reduce_slabs_run(slabs, nslab, per, groups, n, tmp, stream)) return rc;
+    slabs = tmp;
+    nslab = groups;
+  }
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)Cs, (unsigned)((Cl + 63) / 64)), dim3(256), 0, stream, slabs, nslab, Cs,
+                     Cl, dw);
+  SVS_CHECK_LAUNCH("wgrad_reduce");
+  return SVS_OK;
 }
 
 int svs_wgrad_gemm_run(const float* s, long lds, int B, int Hs, int Ws, int Cs, const float* l, long ldl, int Hl,
@@ -345,6 +502,16 @@ int svs_wgrad_gemm_run(const float* s, long lds, int B, int Hs, int Ws, int Cs, 
   if (!ws || ws_bytes < need) {
     svs_set_error("%s: workspace too small (%zu < %zu)", who, ws_bytes, need);
     return SVS_ERR_WORKSPACE;
+  }
+  const WgWinPlan wp = plan_wgrad_window(B, Hs, Ws, Cs, Cl);
+  if (wp.use && (long)Hs * Ws * lds * 4 < (1L << 31) && (long)Hl * Wl * ldl * 4 < (1L << 31)) {
+    WgWinArgs wa{s, lds, l, ldl, B, Hs, Ws, Cs, Hl, Wl, Cl, (float*)ws, wp.ntiles, wp.tpb};
+    if (wp.MT == 4) hipLaunchKernelGGL((wgrad_window_kernel<4>), dim3(wp.gx, wp.gy), dim3(256), 0, stream, wa);
+    else hipLaunchKernelGGL((wgrad_window_kernel<2>), dim3(wp.gx, wp.gy), dim3(256), 0, stream, wa);
+    SVS_CHECK_LAUNCH("wgrad_window");
+    pl.ksplit = wp.nslab;
+    if (getenv("SVS_SKIP_REDUCE")) return SVS_OK;
+    return wgrad_reduce_run((const float*)ws, pl.ksplit, Cs, Cl, dw, (float*)ws + (size_t)pl.ksplit * Cs * 25 * Cl, stream);
   }
   WgradArgs a{};
   a.s = s; a.lds = lds; a.Hs = Hs; a.Ws = Ws; a.Cs = Cs;
@@ -369,24 +536,12 @@ int svs_wgrad_gemm_run(const float* s, long lds, int B, int Hs, int Ws, int Cs, 
   }
   SVS_CHECK_LAUNCH("wgrad_gemm");
   if (getenv("SVS_SKIP_REDUCE")) return SVS_OK;             // lets bench.py time the GEMM kernel alone
-  const long n = (long)Cs * 25 * Cl;
-  const float* slabs = (const float*)ws;
-  int nslab = pl.ksplit;
-  if (nslab > 2 * WG_GROUPS) {     // long serial chains per output element: sum in WG_GROUPS parallel groups first
-    float* tmp = (float*)ws + (size_t)pl.ksplit * n;
-    const int per = (nslab + WG_GROUPS - 1) / WG_GROUPS;
-    const int groups = (nslab + per - 1) / per;
-    if (int rc = svs_reduce_slabs_run(slabs, nslab, per, groups, n, tmp, stream)) return rc;
-    slabs = tmp;
-    nslab = groups;
-  }
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)Cs, (unsigned)((Cl + 63) / 64)), dim3(256), 0, stream, slabs, nslab, Cs,
-                     Cl, dw);
-  SVS_CHECK_LAUNCH("wgrad_reduce");
-  return SVS_OK;
+  return wgrad_reduce_run((const float*)ws, pl.ksplit, Cs, Cl, dw, (float*)ws + (size_t)pl.ksplit * Cs * 25 * Cl, stream);
 }
 
 int svs_wgrad_gemm_describe(int B, int Hs, int Ws, int Cs, int Cl, char* buf, size_t n) {
+  const WgWinPlan wp = plan_wgrad_window(B, Hs, Ws, Cs, Cl);
+  if (wp.use) { snprintf(buf, n, "wgrad_window_kernel<%d>", wp.MT); return wp.nslab; }
   const WgradPlan pl = plan_wgrad(B, Hs, Ws, Cs, Cl);
   snprintf(buf, n, "wgrad_gemm_kernel<%d, %d, %d, %d, %s>", pl.BM, pl.BN, pl.cfg == 0 ? 2 : 1, pl.cfg == 0 ? 2 : 4,
            use_wgrad_skip(B, Hs, Ws, Cl, Cs, pl.cfg) ? "true" : "false");

@@ -307,6 +307,25 @@ def test_wgrad_padding_skip(kind, B, H, W, C, N, report, monkeypatch):
     """Weight gradients with batch-innermost pixels and padding-only K-tiles skipped (forced on small shapes), against
     torch fp64; strided operand views."""
     monkeypatch.setenv("SVS_WGRAD_SKIP", "2")
+    _wgrad_case(kind, B, H, W, C, N, report, "wgrad skip")
+
+
+@pytest.mark.parametrize("kind,B,H,W,C,N", [("enc", 2, 16, 32, 16, 32), ("enc", 1, 18, 40, 32, 64), ("enc", 3, 8, 64, 16, 64),
+                                            ("dec", 2, 8, 16, 64, 16), ("dec", 1, 6, 20, 128, 32), ("dec", 2, 4, 16, 32, 16),
+                                            ("enc", 1, 34, 34, 32, 128)])
+def test_wgrad_window_kernel(kind, B, H, W, C, N, report, monkeypatch):
+    """The LDS-window weight-gradient kernel (shallow layers), forced on small and ragged shapes."""
+    monkeypatch.setenv("SVS_WGRAD_WINDOW", "2")
+    buf = ctypes.create_string_buffer(128)
+    if kind == "enc":
+        L().svs_describe_plan(2, B, (H + 1) // 2, (W + 1) // 2, N, 0, 0, C, buf, 128)
+    else:
+        L().svs_describe_plan(2, B, H, W, C, 0, 0, N, buf, 128)
+    assert buf.value.decode().startswith("wgrad_window_kernel"), buf.value
+    _wgrad_case(kind, B, H, W, C, N, report, "wgrad window")
+
+
+def _wgrad_case(kind, B, H, W, C, N, report, tag):
     if kind == "enc":
         x = rnd((B, C, H, W), 80).double()
         w = rnd((N, C, 5, 5), 81, -0.1, 0.1).double().requires_grad_(True)
@@ -331,7 +350,7 @@ def test_wgrad_padding_skip(kind, B, H, W, C, N, report, monkeypatch):
         ws = ws_tensor(L().svs_block_bwd_weight_workspace_bytes(B, H, W, C, N))
         _lib.check(L().svs_dec_block_bwd_weight(xd.data_ptr(), C + 8, B, H, W, C, dyd.data_ptr(), N + 4, Ho, Wo, N, dw.data_ptr(), None,
                                                 ws.data_ptr(), ws.numel(), S()))
-    assert report(f"wgrad skip {kind} B{B} {H}x{W} C{C} N{N}", relerr(dw, w.grad), 2e-5)
+    assert report(f"{tag} {kind} B{B} {H}x{W} C{C} N{N}", relerr(dw, w.grad), 2e-5)
 
 
 def test_single_channel_bwd(report):
