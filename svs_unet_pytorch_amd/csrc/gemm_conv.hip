@@ -4,7 +4,7 @@
 //   MODE_GATHER  y[b,oh,ow,n] = sum_{kh,kw,c} x[b,2oh-2+kh,2ow-2+kw,c] * wp[n][kh][kw][c]
 //                -> Conv2d forward (reference model.py:48-74) and ConvTranspose2d backward-data.
 //   MODE_PARITY  y[b,2a+ph,2c+pw,n] = sum_{th,tw,c} x[b,a+1-th,c+1-tw,c] * wp[p][n][th][tw][c]
-//                (blockIdx.y = p = 2*ph+pw, 9/6/6/4 taps: the four stride-1 sub-convolutions of a
+//                (blockIdx.z = p = 2*ph+pw, 9/6/6/4 taps: the four stride-1 sub-convolutions of a
 //                stride-2 transposed conv) -> ConvTranspose2d forward (model.py:79-109) and Conv2d
 //                backward-data.
 // GEMM view: M = output pixels of the (parity) grid, N = output channels, K = taps x input channels,
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs p) {
   int Ha, Wa;                      // rows / cols of the M grid
   const float* wp = p.wp;
   if (MODE == MODE_PARITY) {
-    const int par = blockIdx.y;
+    const int par = blockIdx.z;             // classes outermost in dispatch order: all the long (9-tap) blocks start first
     ph = par >> 1; pw = par & 1;
     nth = 3 - ph; ntw = 3 - pw;
     Ha = (p.Ho - ph + 1) >> 1; Wa = (p.Wo - pw + 1) >> 1;
@@ -89,8 +89,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs p) {
   if (m0 >= M) return;             // parity classes of odd-sized outputs are smaller
   const int cpt = p.C >> 4;        // K-tiles per tap
   const int nkt = ntaps * cpt;
-  const int kt_begin = (int)((long)nkt * blockIdx.z / p.ksplit);
-  const int kt_end = (int)((long)nkt * (blockIdx.z + 1) / p.ksplit);
+  const int kt_begin = (int)((long)nkt * blockIdx.y / p.ksplit);
+  const int kt_end = (int)((long)nkt * (blockIdx.y + 1) / p.ksplit);
   const long Kw = (long)ntaps * p.C;   // weight row length
 
   // ---- per-thread staging rows -----------------------------------------------------------------
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs p) {
 
   // ---- epilogue: C/D map of the 16x16 MFMA: col = lane & 15, row = 4*(lane>>4) + reg ------------
   const bool split = p.ksplit > 1;
-  float* const slab = split ? p.slab + (long)blockIdx.z * ((long)p.B * p.Ho * p.Wo) * p.N : nullptr;
+  float* const slab = split ? p.slab + (long)blockIdx.y * ((long)p.B * p.Ho * p.Wo) * p.N : nullptr;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -698,7 +698,7 @@ static ConvPlan plan_conv(int mode, long Mmax, int N, int nkt_min, bool narrow =
 
 template <int MODE>
 static int launch_conv_gemm(const ConvGemmArgs& a, const ConvPlan& pl, hipStream_t stream, bool skip) {
-  dim3 grid((unsigned)(pl.mtiles * (a.N / pl.BN)), (unsigned)pl.grid_y, (unsigned)pl.ksplit);
+  dim3 grid((unsigned)(pl.mtiles * (a.N / pl.BN)), (unsigned)pl.ksplit, (unsigned)pl.grid_y);      // (tiles, K-splits, parity classes)
   dim3 block(256);
   if (skip) {                                // batch-innermost rows + padding-tap skipping (deep levels)
     switch (pl.cfg) {

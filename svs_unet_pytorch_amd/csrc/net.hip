@@ -561,8 +561,8 @@ static int train_backward_impl(const ParamView& v, float* grads, const float* mi
   if ((rc = fork())) return rc;
   if ((rc = svs_wgrad_c1_run(t.cat[1], 16, B, g.h[1], g.w[1], 32, t.d_logit, g.h[0], g.w[0], G(44), wscratch, wscratch_bytes, wstream,
                              "deconv6 bwd_weight", half1))) return rc;
+  if ((rc = svs_sum_run(t.d_logit, g.P[0], G(45), wscratch, wscratch_bytes, wstream))) return rc;      // deconv6 bias gradient
   if ((rc = forked())) return rc;
-  if ((rc = svs_sum_run(t.d_logit, g.P[0], G(45), t.scratch, t.scratch_bytes, stream))) return rc;
   if ((rc = svs_conv_c1_run(t.d_logit, B, g.h[0], g.w[0], v.w[11], nullptr, nullptr, nullptr, 0.f, t.dcat[1], 16, 32, 0, stream,
                             "deconv6 bwd_data", half1))) return rc;
   // decoders 5..1
