@@ -40,6 +40,8 @@ struct ConvGemmArgs {
   float* slab;                    // [ksplit][B*Ho*Wo][N] partial sums when ksplit > 1
   int tap_inner;                  // K-tile order: 1 = channel chunk outer / tap inner, 0 = tap outer / chunk inner
   int cpt_shift;                  // log2(C / 16) when that is a power of two, else -1
+  float* stats;                   // non-split kernels: BatchNorm partials of the output, [row][2][N] (row = class * mtiles + mtile
+                                  // for the GEMM, = block for the window kernel); null = off
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 3); }
@@ -86,7 +88,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs p) {
   const int ntile_n = p.N / BN;
   const long m0 = (long)(blockIdx.x / ntile_n) * BM;
   const int n0 = (blockIdx.x % ntile_n) * BN;
-  if (m0 >= M) return;             // parity classes of odd-sized outputs are smaller
+  if (m0 >= M) {                   // parity classes of odd-sized outputs are smaller
+    if (p.stats && p.ksplit == 1) {                // their statistics row must still exist
+      float* out = p.stats + ((long)blockIdx.z * (gridDim.x / ntile_n) + blockIdx.x / ntile_n) * 2 * p.N + n0;
+      for (int c = threadIdx.x; c < BN; c += 256) { out[c] = 0.f; out[p.N + c] = 0.f; }
+    }
+    return;
+  }
   const int cpt = p.C >> 4;        // K-tiles per tap
   const int nkt = ntaps * cpt;
   const int kt_begin = (int)((long)nkt * blockIdx.y / p.ksplit);
@@ -248,6 +256,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs p) {
 
   // ---- epilogue: C/D map of the 16x16 MFMA: col = lane & 15, row = 4*(lane>>4) + reg ------------
   const bool split = p.ksplit > 1;
+  float ssum[TN], ssq[TN];               // per-lane column sums of the values written (BatchNorm statistics)
+#pragma unroll
+  for (int j = 0; j < TN; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
   float* const slab = split ? p.slab + (long)blockIdx.y * ((long)p.B * p.Ho * p.Wo) * p.N : nullptr;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -286,8 +297,29 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs p) {
           float* dst = p.y + opix * p.ldy + n;
           if (p.accumulate) v += *dst;
           *dst = v;
+          ssum[j] += v;
+          ssq[j] += v * v;
         }
       }
+    }
+  }
+  if (p.stats && !split) {
+    // column sums of this tile: over the four 4-row groups of a wave (lanes 16 apart), then over the WM waves
+    __shared__ float st[2][WM][BN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      ssum[j] += __shfl_xor(ssum[j], 16, 64); ssum[j] += __shfl_xor(ssum[j], 32, 64);
+      ssq[j] += __shfl_xor(ssq[j], 16, 64); ssq[j] += __shfl_xor(ssq[j], 32, 64);
+      if (q == 0) { st[0][wm][wn * (TN * 16) + j * 16 + lrow] = ssum[j]; st[1][wm][wn * (TN * 16) + j * 16 + lrow] = ssq[j]; }
+    }
+    __syncthreads();
+    float* out = p.stats + ((long)blockIdx.z * (gridDim.x / ntile_n) + blockIdx.x / ntile_n) * 2 * p.N + n0;
+    for (int c = t; c < BN; c += 256) {
+      float a = 0.f, b2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) { a += st[0][w][c]; b2 += st[1][w][c]; }
+      out[c] = a;
+      out[p.N + c] = b2;
     }
   }
 }
@@ -533,8 +565,16 @@ __global__ __launch_bounds__(256) void parity_window_kernel(ConvGemmArgs p) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][k], fb[s_ & 1][cc][j][k], acc[i][j], 0, 0, 0);
     }
   };
+  struct ColStat { float s[TN], q[TN]; };     // per-lane channel sums of what a class stores (BatchNorm statistics); returned
+                                              // by value: an array captured by reference in a lambda ends up in scratch
+  ColStat wst;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) { wst.s[j] = 0.f; wst.q[j] = 0.f; }
   // rows q*4 + r of row tile i = anchor (th0 + 2*wave + i, tw0 + q*4 + r); column lrow (+16j) = output channel
-  auto store_class = [&](int par, const f32x4 (&acc)[TM][TN]) {
+  auto store_class = [&](int par, const f32x4 (&acc)[TM][TN]) -> ColStat {
+    ColStat cs;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { cs.s[j] = 0.f; cs.q[j] = 0.f; }
     const int ph = par >> 1, pw = par & 1;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -559,9 +599,17 @@ __global__ __launch_bounds__(256) void parity_window_kernel(ConvGemmArgs p) {
           float* dst = p.y + opix * p.ldy + n;
           if (p.accumulate) v += *dst;
           *dst = v;
+          cs.s[j] += v;
+          cs.q[j] += v * v;
         }
       }
     }
+    return cs;
+  };
+  auto add_stat = [](ColStat a, const ColStat& b) -> ColStat {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { a.s[j] += b.s[j]; a.q[j] += b.q[j]; }
+    return a;
   };
   auto zero = [&](f32x4 (&acc)[TM][TN]) {
 #pragma unroll
@@ -580,7 +628,7 @@ __global__ __launch_bounds__(256) void parity_window_kernel(ConvGemmArgs p) {
       if constexpr (s_ + 1 < 25) load_b(std::integral_constant<int, (s_ + 1 < 25 ? s_ + 1 : 0)>{}, 0);
       if constexpr (CC >= 4) __builtin_amdgcn_sched_barrier(0);
       step(sc, acc);
-      if constexpr (s_ == 24 || s_ + 1 == POFF[par < 3 ? par + 1 : 3]) store_class(par, acc);
+      if constexpr (s_ == 24 || s_ + 1 == POFF[par < 3 ? par + 1 : 3]) wst = add_stat(wst, store_class(par, acc));
       if constexpr (CC >= 4) __builtin_amdgcn_sched_barrier(0);     // (32-channel steps are too short to fence)
     });
   } else {                                     // several phases share the window buffer: all four classes stay live
@@ -601,7 +649,23 @@ __global__ __launch_bounds__(256) void parity_window_kernel(ConvGemmArgs p) {
       });
     }
 #pragma unroll
-    for (int par = 0; par < 4; ++par) store_class(par, acc[par]);
+    for (int par = 0; par < 4; ++par) wst = add_stat(wst, store_class(par, acc[par]));
+  }
+  if (p.stats) {                               // this block's row of BatchNorm partials: [2][N]
+    __shared__ float st[2][4][TN * 16];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float a = wst.s[j], b2 = wst.q[j];
+      a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+      b2 += __shfl_xor(b2, 16, 64); b2 += __shfl_xor(b2, 32, 64);
+      if (q == 0) { st[0][wave][j * 16 + lrow] = a; st[1][wave][j * 16 + lrow] = b2; }
+    }
+    __syncthreads();
+    if (t < TN * 16) {
+      float* out = p.stats + (long)blockIdx.x * 2 * (TN * 16);
+      out[t] = (st[0][0][t] + st[0][1][t]) + (st[0][2][t] + st[0][3][t]);
+      out[TN * 16 + t] = (st[1][0][t] + st[1][1][t]) + (st[1][2][t] + st[1][3][t]);
+    }
   }
 }
 
@@ -767,7 +831,7 @@ static int use_tap_skip(int mode, int B, int C, int Wo, int N, int cfg) {
 int svs_conv_gemm_run(int mode, const float* x, long ldx, int B, int H, int W, int C, const float* wp,
                       const float* bias, const float* scale, const float* shift, float slope, float* y, long ldy,
                       int Ho, int Wo, int N, int accumulate, void* ws, size_t ws_bytes, hipStream_t stream,
-                      const char* who, float* stats, int stats_cap, int* stats_nblk) {
+                      const char* who, float* stats, int stats_cap, int* stats_nblk) {   // stats_cap: capacity of `stats` in floats
   if (stats_nblk) *stats_nblk = 0;
   int rc = check_gemm_args(who, x, ldx, B, H, W, C, wp, y, ldy, Ho, Wo, N);
   if (rc) return rc;
@@ -819,9 +883,11 @@ int svs_conv_gemm_run(int mode, const float* x, long ldx, int B, int H, int W, i
     else if (N == 32 && mode == MODE_PARITY && C >= 128) direct = 1;
   }
   if (const char* e = getenv("SVS_CONV_DIRECT")) { const int f = atoi(e); if (f == 0 || (N <= 32 && Mmax >= 16384)) direct = f; }  // sweeps
+  const bool want_stats = stats && stats_nblk && !scale && !accumulate;
   if (window) {
     a.ksplit = 1; a.slab = nullptr;
     dim3 grid((unsigned)((long)B * ((H + 7) / 8) * ((W + 15) / 16)));
+    if (want_stats && (long)grid.x * 2 * N <= stats_cap) { a.stats = stats; *stats_nblk = (int)grid.x; }
 #define SVS_LAUNCH_WINDOW(C_, CW_, TN_) hipLaunchKernelGGL((parity_window_kernel<C_, CW_, TN_>), grid, dim3(256), 0, stream, a)
     if (N == 16) {
       if (C == 32) SVS_LAUNCH_WINDOW(32, 32, 1); else if (C == 64) SVS_LAUNCH_WINDOW(64, 64, 1); else SVS_LAUNCH_WINDOW(128, 64, 1);
@@ -849,6 +915,10 @@ int svs_conv_gemm_run(int mode, const float* x, long ldx, int B, int H, int W, i
     return SVS_OK;
   }
   const int skip = use_tap_skip(mode, B, C, Wo, N, pl.cfg);
+  if (want_stats && pl.ksplit == 1 && pl.mtiles * pl.grid_y * 2 * N <= stats_cap) {
+    a.stats = stats;                         // one row of partials per (parity class, M-tile)
+    *stats_nblk = (int)(pl.mtiles * pl.grid_y);
+  }
   rc = (mode == MODE_GATHER) ? launch_conv_gemm<MODE_GATHER>(a, pl, stream, skip) : launch_conv_gemm<MODE_PARITY>(a, pl, stream, skip);
   if (rc) return rc;
   if (pl.ksplit > 1 && !getenv("SVS_SKIP_REDUCE")) {      // (the switch lets bench.py time the GEMM kernel alone)
@@ -856,8 +926,9 @@ int svs_conv_gemm_run(int mode, const float* x, long ldx, int B, int H, int W, i
     int grid = (int)((total4 + 255) / 256);
     if (grid > 2048) grid = 2048;
     // fused BatchNorm statistics: stats[grid][2][N] must fit the caller's buffer (stats_cap rows)
-    const bool fuse = stats && stats_nblk && stats_cap > 0 && N % 4 == 0 && N <= 1024 && 256 % (N / 4) == 0 && !scale && !accumulate;
-    if (fuse && grid > stats_cap) grid = stats_cap;
+    const bool fuse = stats && stats_nblk && stats_cap >= 2 * N && N % 4 == 0 && N <= 1024 && 256 % (N / 4) == 0 && !scale && !accumulate;
+    if (fuse && grid > 512) grid = 512;
+    if (fuse && (long)grid * 2 * N > stats_cap) grid = stats_cap / (2 * N);
     hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(grid), dim3(256), 0, stream, a.slab, pl.ksplit, P, N, bias, scale,
                        shift, slope, y, ldy, accumulate, fuse ? stats : nullptr);
     SVS_CHECK_LAUNCH("splitk_epilogue");

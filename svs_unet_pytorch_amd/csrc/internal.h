@@ -8,8 +8,9 @@ int svs_conv_gemm_run(int mode, const float* x, long ldx, int B, int H, int W, i
                       const float* bias, const float* scale, const float* shift, float slope, float* y, long ldy,
                       int Ho, int Wo, int N, int accumulate, void* ws, size_t ws_bytes, hipStream_t stream,
                       const char* who, float* stats = nullptr, int stats_cap = 0, int* stats_nblk = nullptr);
-// stats / stats_cap / stats_nblk: when the planner splits K, the epilogue kernel also writes svs_bn_stats-style
-// partials of the output into stats[<= stats_cap][2][N] and reports the number of rows (0: not produced).
+// stats / stats_cap / stats_nblk: the kernel that writes the output (split-K epilogue, GEMM epilogue or window kernel) also
+// writes svs_bn_stats-style partials of it into stats[rows][2][N] (stats_cap = capacity in floats) and reports the number
+// of rows (0: not produced, e.g. the LDS-free direct kernel).
 int svs_bn_finalize_run(const void* partial, int nblk, long P, int C, float eps, float momentum, float* running_mean,
                         float* running_var, long long* nbt, float* save_mean, float* save_invstd, hipStream_t stream);
 struct SvsSumJobs { int njobs; const float* partial[12]; int nblk[12]; int C[12]; float* out[12]; };

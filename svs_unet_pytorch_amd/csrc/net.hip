@@ -439,7 +439,7 @@ static int train_forward_impl(const ParamView& v, float* bn_buffers, int64_t* nb
                               const Geo& g, const TrainWs& t, float* mask, hipStream_t stream) {
   const int B = g.B;
   int rc;
-  const int fused_rows = getenv("SVS_TRAIN_UNFUSED") ? 0 : SVS_FUSED_STATS_ROWS;     // A/B switch
+  const int fused_rows = getenv("SVS_TRAIN_UNFUSED") ? 0 : (int)(t.bnws_bytes / sizeof(float));     // capacity (floats) for fused BatchNorm partials; A/B switch
   SideStream* sd = getenv("SVS_TRAIN_ONE_STREAM") ? nullptr : side_stream();          // A/B switch
   // weight packings for this step (weights change every optimiser step)
   {
