@@ -390,7 +390,13 @@ static SideStream* side_stream() {
   std::lock_guard<std::mutex> lock(g_side_mutex);
   if (!g_side[dev]) {
     SideStream* sd = new SideStream();
-    bool ok = hipStreamCreateWithFlags(&sd->s, hipStreamNonBlocking) == hipSuccess;
+    // HIGHEST priority (measured: 3.75 ms per step against 3.77 at normal and 3.83 at low priority): the weight-gradient
+    // GEMMs then start as soon as their d_raw exists and are out of the way when the main stream reaches its next GEMM
+    int least = 0, greatest = 0;
+    bool ok = hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess;
+    int prio = greatest;
+    if (const char* e = getenv("SVS_SIDE_PRIORITY")) prio = atoi(e);                 // sweeps only
+    ok = ok && hipStreamCreateWithPriority(&sd->s, hipStreamNonBlocking, prio) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&sd->sync, hipEventDisableTiming) == hipSuccess;
     for (int i = 0; i < 4 && ok; ++i)
       ok = hipEventCreateWithFlags(&sd->fork[i], hipEventDisableTiming) == hipSuccess &&
