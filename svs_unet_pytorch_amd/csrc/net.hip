@@ -311,7 +311,8 @@ struct TrainWs {
   float* mean[11]; float* invstd[11];
   float* wfwd[12]; float* wbwd[12];       // packed weights (null where torch's layout is read directly)
   float* dcat[6]; float* dc6;
-  float* d_raw; float* d_raw2; float* d_logit; float* mask;   // d_raw2: second buffer so that the side stream's wgrad can trail
+  float* d_raw; float* d_logit; float* mask;
+  float* d_raw_l[11];                     // one d_raw per BatchNorm layer: the side stream's weight gradients trail freely
   float* bnws; size_t bnws_bytes;
   float* dbias_part[11];                  // per-layer partial sums of d_raw (bias gradients), reduced in one batched pass
   float* scratch; size_t scratch_bytes;
@@ -335,7 +336,10 @@ static TrainWs train_layout(const Geo& g, void* ws) {
   size_t dmax = 0;
   for (int k = 1; k <= 6; ++k) if ((size_t)g.P[k] * CH[k] > dmax) dmax = (size_t)g.P[k] * CH[k];
   t.d_raw = a.take(dmax);
-  t.d_raw2 = a.take(dmax);
+  for (int l = 0; l < 11; ++l) {
+    const int lvl = (l < 6) ? l + 1 : 5 - (l - 6);
+    t.d_raw_l[l] = a.take((size_t)g.P[lvl] * bn_channels(l));
+  }
   t.d_logit = a.take((size_t)g.P[0]);
   t.mask = a.take((size_t)g.P[0]);
   size_t bb = 0;
@@ -535,30 +539,26 @@ static int train_backward_impl(const ParamView& v, float* grads, const float* mi
   const hipStream_t wstream = sd ? sd->s : stream;                  // where the weight gradients run
   float* const wscratch = sd ? t.scratch2 : t.scratch;
   const size_t wscratch_bytes = sd ? t.scratch2_bytes : t.scratch_bytes;
-  float* const draw[2] = {t.d_raw, sd ? t.d_raw2 : t.d_raw};
   // forks so far in this backward pass (kept in the SideStream across the calls of a split pass, which must come in
-  // order on one host thread); fork n uses event slot n & 3 and d_raw buffer n & 1
+  // order on one host thread); fork n uses event slot n & 3.  Every layer has a d_raw buffer of its own, so the main
+  // stream never waits for a weight gradient before the end of the pass (an event pair per layer measured dearer than
+  // the 0.2 GB of workspace).
   int nfork_local = 0;
   int& nfork = sd ? sd->nfork : nfork_local;
   if (parts & 1) nfork = 0;
-  // d_raw buffer of the next layer: the weight gradient that read it two layers ago must have finished
-  auto next_draw = [&]() -> float* {
-    if (sd && nfork >= 2 && hipStreamWaitEvent(stream, sd->done[(nfork - 2) & 3], 0) != hipSuccess) return nullptr;
-    return draw[nfork & 1];
-  };
+  auto layer_draw = [&](int l) -> float* { return sd ? t.d_raw_l[l] : t.d_raw; };
   auto fork = [&]() -> int {                 // the side stream may start once everything queued on `stream` so far is done
     if (!sd) return SVS_OK;
     SVS_HIP(hipEventRecord(sd->fork[nfork & 3], stream));
     SVS_HIP(hipStreamWaitEvent(sd->s, sd->fork[nfork & 3], 0));
     return SVS_OK;
   };
-  auto forked = [&]() -> int {               // marks the end of this layer's side work
-    if (sd) SVS_HIP(hipEventRecord(sd->done[nfork & 3], sd->s));
-    ++nfork;
-    return SVS_OK;
-  };
-  auto join = [&]() -> int {                 // `stream` waits for all side work of this call
-    if (sd && nfork > 0) SVS_HIP(hipStreamWaitEvent(stream, sd->done[(nfork - 1) & 3], 0));
+  auto forked = [&]() -> int { ++nfork; return SVS_OK; };
+  auto join = [&]() -> int {                 // `stream` waits for all side work enqueued so far
+    if (sd && nfork > 0) {
+      SVS_HIP(hipEventRecord(sd->done[0], sd->s));
+      SVS_HIP(hipStreamWaitEvent(stream, sd->done[0], 0));
+    }
     return SVS_OK;
   };
   if (parts & 1) {
@@ -578,8 +578,7 @@ static int train_backward_impl(const ParamView& v, float* grads, const float* mi
     const int lin = 6 - j, lout = 5 - j, l = 6 + j, N = DEC_N[j], C = DEC_C[j];
     const float* x = (j == 0) ? t.c6 : t.cat[lin];
     const View dyv = cat_half(t.dcat, g, lout, 0);
-    float* const d_raw = next_draw();
-    SVS_REQUIRE(d_raw, "svs_unet_train_backward: hipStreamWaitEvent failed");
+    float* const d_raw = layer_draw(l);
     rc = svs_bn_bwd_run(dyv.p, dyv.ld, t.raw_d[j], N, g.P[lout], N, (long)g.h[lout] * g.w[lout], v.gamma[l], v.beta[l],
                         t.mean[l], t.invstd[l], 0.f, drop ? drop + drop_off[j] : nullptr, d_raw, G(24 + 4 * j + 2), G(24 + 4 * j + 3),
                         G(24 + 4 * j + 1), t.bnws, t.bnws_bytes, stream, unfused ? nullptr : t.dbias_part[l], &sums);   // + bias gradient (sum of d_raw)
@@ -602,8 +601,7 @@ static int train_backward_impl(const ParamView& v, float* grads, const float* mi
     const int l = k - 1, N = CH[k], C = CH[k - 1];
     const View dyv = (k == 6) ? View{t.dc6, 512} : cat_half(t.dcat, g, k, 1);
     const float* dy = dyv.p; const long lddy = dyv.ld;
-    float* const d_raw = next_draw();
-    SVS_REQUIRE(d_raw, "svs_unet_train_backward: hipStreamWaitEvent failed");
+    float* const d_raw = layer_draw(l);
     rc = svs_bn_bwd_run(dy, lddy, t.raw_e[k], N, g.P[k], N, (long)g.h[k] * g.w[k], v.gamma[l], v.beta[l], t.mean[l], t.invstd[l],
                         LEAKY, nullptr, d_raw, G(4 * l + 2), G(4 * l + 3), G(4 * l + 1), t.bnws, t.bnws_bytes, stream,
                         unfused ? nullptr : t.dbias_part[l], &sums);
