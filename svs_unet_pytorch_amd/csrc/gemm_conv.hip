@@ -812,13 +812,13 @@ static int use_parity_window(int mode, int B, int H, int W, int C, int N, long l
 
 static bool narrow_level(int mode, int B, int C, int Wo, int N) {
   if (getenv("SVS_CONV_SKIP") || getenv("SVS_CONV_KORDER")) return false;          // sweeps and tests keep the generic tiles
-  return N > 32 && (C & (C - 1)) == 0 && B >= 32 && ((mode == MODE_GATHER) ? Wo : (Wo + 1) / 2) <= 8;
+  return N > 32 && (C & (C - 1)) == 0 && B >= 16 && ((mode == MODE_GATHER) ? Wo : (Wo + 1) / 2) <= 8;
 }
 
 // narrow levels: batch-innermost rows so that whole taps of an M-tile fall into the padding and are skipped
 static int use_tap_skip(int mode, int B, int C, int Wo, int N, int cfg) {
   const bool can = N > 32 /* tap-outer K order */ && (C & (C - 1)) == 0 && (cfg == 0 || cfg == 1 || cfg == 4 || cfg == 5);
-  int skip = can && B >= 32 && ((mode == MODE_GATHER) ? Wo : (Wo + 1) / 2) <= 8;
+  int skip = can && B >= 16 && ((mode == MODE_GATHER) ? Wo : (Wo + 1) / 2) <= 8;
   if (const char* e = getenv("SVS_CONV_SKIP")) {     // sweeps and tests: 0 = never, 2 = whenever the kernel supports it
     const int f = atoi(e);
     skip = (f == 0) ? 0 : (f == 2) ? can : skip;
