@@ -750,7 +750,10 @@ static ConvPlan plan_conv(int mode, long Mmax, int N, int nkt_min, bool narrow =
   const long target = (mode == MODE_PARITY) ? 1024 : 768;
   if (blocks < ((mode == MODE_PARITY) ? 768 : 384)) {
     ks = (int)((target + blocks - 1) / blocks);
-    const int cap = nkt_min / 8 > 1 ? nkt_min / 8 : 1;   // keep >= 8 K-tiles per split
+    // keep >= 8 K-tiles per split (16 in gather mode: with K = 25 or 50 tiles -- conv2 / conv3 at batch 16 -- finer
+    // splits lose more in the epilogue than they win in occupancy)
+    const int per = (mode == MODE_GATHER) ? 16 : 8;
+    const int cap = nkt_min / per > 1 ? nkt_min / per : 1;
     if (ks > cap) ks = cap;
     if (ks > 64) ks = 64;
     if (ks < 1) ks = 1;
@@ -801,7 +804,7 @@ static int check_gemm_args(const char* who, const float* x, long ldx, int B, int
 static int use_parity_window(int mode, int B, int H, int W, int C, int N, long ldx) {
   const bool eligible = mode == MODE_PARITY && (N == 16 || N == 32) && (C == 32 || C == 64 || C == 128) &&
                         ((long)H * W * ldx) * 4 < (1L << 31);
-  const bool fills_gpu = H >= 8 && W >= 16 && (long)B * ((H + 7) / 8) * ((W + 15) / 16) >= 512;
+  const bool fills_gpu = H >= 8 && W >= 16 && (long)B * ((H + 7) / 8) * ((W + 15) / 16) >= 128;   // (B=16 sweep: still ahead of the direct kernel at 128 blocks)
   int window = eligible && fills_gpu;
   if (const char* e = getenv("SVS_CONV_WINDOW")) {     // sweeps and tests: 0 = never, 2 = whenever the shape is eligible
     const int f = atoi(e);
