@@ -410,8 +410,6 @@ static SideStream* side_stream() {
   }
   return g_side[dev];
 }
-#define SVS_HIP(call)                                                                     \
-  do { hipError_t e_ = (call); if (e_ != hipSuccess) { svs_set_error("%s: %s", #call, hipGetErrorString(e_)); return SVS_ERR_INVALID; } } while (0)
 
 extern "C" size_t svs_unet_train_workspace_bytes(int B, int H, int W) {
   Geo g;
