@@ -46,6 +46,13 @@ int svs_fill_uniform(float* out, int64_t n, uint32_t seed, uint64_t offset, floa
  * Stands in for SpectrogramDataset.__getitem__ (train.py:86-143) in every synthetic config. */
 int svs_fill_tiles(float* mix, float* voc, int B, int H, int W, int64_t first_tile, hipStream_t stream);
 /* Dropout2d(0.5) keep-masks (model.py:83,89,95,101,107): out[b*C+c] in {0, 2}. */
+/* Training tiles from spectrograms kept in HBM -- SpectrogramDataset.__getitem__, train.py:86-143 (L1 path: magnitudes
+ * only).  mix_songs / voc_songs: flat buffers, song s = rows 1..F of its (F+1, T_s) file (DC row dropped, train.py:109-112)
+ * at float offset[s], (F, T_s) row-major.  Sample b = song[b], columns [start[b], start[b]+seg) of both tracks (shared
+ * start, train.py:121), right zero-padded where the song ends (train.py:129-135).  mix / voc: (B, 1, F, seg). */
+int svs_crop_tiles(const float* mix_songs, const float* voc_songs, const int64_t* offset, const int32_t* frames,
+                   const int32_t* song, const int32_t* start, int B, int F, int seg, float* mix, float* voc,
+                   hipStream_t stream);
 int svs_dropout_mask(float* out, int B, int C, int layer, uint32_t seed, int step, int rank, hipStream_t stream);
 /* The five decoder masks of one step in one launch: out = [B*256 | B*128 | B*64 | B*32 | B*16] floats, each block
  * bit-identical to svs_dropout_mask(layer = 0..4) -- the layout svs_unet_train_* take as `drop`. */

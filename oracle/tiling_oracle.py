@@ -53,3 +53,21 @@ def separate(mix_spec: np.ndarray, mask_fn, seg_len: int = 128, vocal_solo: bool
         return None
     full = np.concatenate(pieces, axis=1)
     return np.concatenate([np.zeros((1, full.shape[1]), np.float32), full], axis=0)
+
+
+def crop_item(mix_file, voc_file, start, seg_len=128):
+    """SpectrogramDataset.__getitem__ of the reference (train.py:86-143), magnitudes only, with the random start passed in
+    (the reference draws it with random.randint(0, T - seg_len), train.py:121; that module builds the auraloss criterion at
+    import, train.py:26, so it cannot be imported here and this restatement is pinned by reading only): rows 1.. of the (513, T) files, columns
+    [start, start + seg_len) when T > seg_len, else the whole song right-padded with zeros (train.py:129-135).
+    Returns mix, voc of shape (1, 512, seg_len) float32."""
+    import numpy as np
+    mix, voc = np.asarray(mix_file)[1:, :], np.asarray(voc_file)[1:, :]
+    T = mix.shape[1]
+    if T > seg_len:
+        mix, voc = mix[:, start:start + seg_len], voc[:, start:start + seg_len]
+    else:
+        pad = ((0, 0), (0, seg_len - T))
+        mix, voc = np.pad(mix, pad), np.pad(voc, pad)
+    return mix[np.newaxis].astype(np.float32), voc[np.newaxis].astype(np.float32)
+

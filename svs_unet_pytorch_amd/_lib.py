@@ -31,6 +31,7 @@ _SIGS = {
     "svs_last_error_string": (C.c_char_p, []),
     "svs_fill_uniform": (I, [P, L, U32, U64, F, F, P]),
     "svs_fill_tiles": (I, [P, P, I, I, I, L, P]),
+    "svs_crop_tiles": (I, [P, P, P, P, P, P, I, I, I, P, P, P]),
     "svs_dropout_mask": (I, [P, I, I, I, U32, I, I, P]),
     "svs_dropout_masks_all": (I, [P, I, U32, I, I, P]),
     "svs_pack_weight_gather": (I, [P, P, I, I, P]),

@@ -691,3 +691,44 @@ extern "C" int svs_dropout_mask(float* out, int B, int C, int layer, uint32_t se
   SVS_CHECK_LAUNCH("dropout_mask");
   return SVS_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Training tiles from spectrograms resident in HBM (train.py:86-143, SpectrogramDataset.__getitem__): sample b is
+// rows 1..F of song[b]'s (F+1, T) magnitude file -- the DC row is already dropped when the song is uploaded -- columns
+// [start[b], start[b] + seg), right zero-padded when the song is shorter; mixture and vocal share the start.
+// songs_*: one flat buffer per track type, song s at offset[s], (F, T_s) row-major.  One thread = 4 frames.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void crop_tiles_kernel(const float* __restrict__ mix_songs, const float* __restrict__ voc_songs,
+                                                         const long long* __restrict__ offset, const int* __restrict__ frames,
+                                                         const int* __restrict__ song, const int* __restrict__ start, int B,
+                                                         int F, int seg, float* __restrict__ mix, float* __restrict__ voc) {
+  const long total = (long)B * F * (seg / 4);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int t4 = (int)(i % (seg / 4));
+    const long row = i / (seg / 4);
+    const int f = (int)(row % F), b = (int)(row / F);
+    const int s = song[b], T = frames[s], st = start[b];
+    const long src = offset[s] + (long)f * T + st + 4 * t4;
+    f32x4 m, v;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const bool in = st + 4 * t4 + k < T;
+      m[k] = in ? mix_songs[src + k] : 0.f;
+      v[k] = in ? voc_songs[src + k] : 0.f;
+    }
+    *(f32x4*)(mix + row * seg + 4 * t4) = m;
+    *(f32x4*)(voc + row * seg + 4 * t4) = v;
+  }
+}
+
+extern "C" int svs_crop_tiles(const float* mix_songs, const float* voc_songs, const int64_t* offset, const int32_t* frames,
+                              const int32_t* song, const int32_t* start, int B, int F, int seg, float* mix, float* voc,
+                              hipStream_t stream) {
+  SVS_REQUIRE(mix_songs && voc_songs && offset && frames && song && start && mix && voc, "svs_crop_tiles: null pointer");
+  SVS_REQUIRE(B > 0 && F > 0 && seg > 0 && seg % 4 == 0 && svs_aligned16(mix) && svs_aligned16(voc), "svs_crop_tiles: bad geometry");
+  hipLaunchKernelGGL(crop_tiles_kernel, dim3(grid_for((long)B * F * (seg / 4))), dim3(256), 0, stream, mix_songs, voc_songs,
+                     (const long long*)offset, frames, song, start, B, F, seg, mix, voc);
+  SVS_CHECK_LAUNCH("crop_tiles");
+  return SVS_OK;
+}
+

@@ -72,6 +72,86 @@ class SpectrogramDataset(Data.Dataset):
         return as_t(mix), as_t(voc), as_t(mix_phase), as_t(voc_phase)
 
 
+def epoch_order(n, shuffle=True, rank=0, world=1, epoch=0):
+    """Item indices of one epoch for one rank -- DataLoader(shuffle=True) on one process, DistributedSampler on several:
+    one permutation of all n items (the same on every rank: seeded by the epoch), padded by wrapping around to a multiple
+    of `world`, rank r taking positions r, r + world, ..."""
+    if shuffle:
+        gen = torch.Generator()
+        gen.manual_seed(epoch if world > 1 else random.getrandbits(31))
+        order = torch.randperm(n, generator=gen).tolist()
+    else:
+        order = list(range(n))
+    if world > 1:
+        total = (n + world - 1) // world * world
+        order = (order + order[:total - n])[rank:total:world]
+    return order
+
+
+class ResidentSpectrograms:
+    """The training set kept in HBM: every song's mixture / vocal magnitude (DC row dropped) is uploaded once, and a batch
+    is cut out of them by one kernel (`svs_crop_tiles`) -- no worker processes, no per-step host-to-device copies of
+    tiles.  Same items and cropping rule as SpectrogramDataset (train.py:86-143): `samples_per_song` items per song,
+    item idx -> song idx % n_songs, one random start shared by mixture and vocal, right zero-padding for short songs.
+    A MUSDB18-sized set is ~1 GB of the 288 GB."""
+
+    def __init__(self, dataset: SpectrogramDataset, device):
+        self.n_songs = len(dataset.file_names)
+        self.samples_per_song = dataset.samples_per_song
+        self.device = device
+        mix_parts, voc_parts, offsets, frames, off = [], [], [], [], 0
+        for name in dataset.file_names:
+            mix = np.load(os.path.join(dataset.mixture_path, name))[1:, :]                   # drop the DC row (train.py:109-112)
+            voc = np.load(os.path.join(dataset.vocal_path, name))[1:, :]
+            if voc.shape != mix.shape:
+                raise ValueError(f"{name}: mixture {mix.shape} and vocal {voc.shape} differ")
+            mix_parts.append(np.ascontiguousarray(mix, dtype=np.float32).reshape(-1))
+            voc_parts.append(np.ascontiguousarray(voc, dtype=np.float32).reshape(-1))
+            offsets.append(off)
+            frames.append(mix.shape[1])
+            off += mix.size
+        self.rows = 512
+        empty = np.zeros(0, np.float32)
+        self.mix = torch.from_numpy(np.concatenate(mix_parts) if mix_parts else empty).to(device)
+        self.voc = torch.from_numpy(np.concatenate(voc_parts) if voc_parts else empty).to(device)
+        self.frames_host = list(frames)
+        self.offsets = torch.tensor(offsets, dtype=torch.int64, device=device)
+        self.frames = torch.tensor(frames, dtype=torch.int32, device=device)
+
+    def __len__(self):
+        return self.n_songs * self.samples_per_song
+
+    def draw(self, items, rng=random):
+        """(song, start) per item: the host side of __getitem__ (train.py:115-127)."""
+        songs = [int(i) % self.n_songs for i in items]
+        starts = [rng.randint(0, self.frames_host[s] - INPUT_LEN) if self.frames_host[s] > INPUT_LEN else 0 for s in songs]
+        return songs, starts
+
+    def crop(self, songs, starts):
+        """mix, voc (B, 1, 512, INPUT_LEN) on the device for the given songs / start frames."""
+        from . import _lib
+        B = len(songs)
+        idx = torch.tensor([songs, starts], dtype=torch.int32).pin_memory().to(self.device, non_blocking=True)
+        mix = torch.empty((B, 1, self.rows, INPUT_LEN), dtype=torch.float32, device=self.device)
+        voc = torch.empty_like(mix)
+        _lib.check(_lib.lib().svs_crop_tiles(self.mix.data_ptr(), self.voc.data_ptr(), self.offsets.data_ptr(), self.frames.data_ptr(),
+                                             idx[0].data_ptr(), idx[1].data_ptr(), B, self.rows, INPUT_LEN, mix.data_ptr(), voc.data_ptr(),
+                                             _lib.stream_ptr()), "svs_crop_tiles")
+        return mix, voc
+
+    def batches(self, batch_size, shuffle=True, rank=0, world=1, epoch=0):
+        """One epoch of (mix, voc) batches: DataLoader(shuffle) / DistributedSampler semantics -- a permutation of all items
+        (the same on every rank, seeded by the epoch), padded to a multiple of `world`, rank r taking items r, r+world, ...;
+        the last batch may be short."""
+        order = epoch_order(len(self), shuffle, rank, world, epoch)
+        for i in range(0, len(order), batch_size):
+            yield self.crop(*self.draw(order[i:i + batch_size]))
+
+    def num_batches(self, batch_size, world=1):
+        per_rank = (len(self) + world - 1) // world
+        return (per_rank + batch_size - 1) // batch_size
+
+
 def l1_terms(model, mix, voc):
     """Eval-mode loss of train.py:329-338 (no gradient)."""
     mask = model(mix)
@@ -111,9 +191,14 @@ def main(argv=None):
         os.makedirs("CKPT", exist_ok=True)
 
     train_dataset = SpectrogramDataset(args.train_folder)
-    sampler = Data.distributed.DistributedSampler(train_dataset, world, rank, shuffle=True) if world > 1 else None
-    train_loader = Data.DataLoader(train_dataset, batch_size=max(args.batch_size // world, 1), num_workers=8,
-                                   shuffle=sampler is None, sampler=sampler, pin_memory=True)
+    sampler = train_loader = resident = None
+    per_rank_batch = max(args.batch_size // world, 1)
+    if os.environ.get("SVS_DATA_LOADER", "resident") == "resident":
+        resident = ResidentSpectrograms(train_dataset, device)            # the whole set lives in HBM (see the class)
+    else:                                                                  # the reference's loader: 8 worker processes
+        sampler = Data.distributed.DistributedSampler(train_dataset, world, rank, shuffle=True) if world > 1 else None
+        train_loader = Data.DataLoader(train_dataset, batch_size=per_rank_batch, num_workers=8,
+                                       shuffle=sampler is None, sampler=sampler, pin_memory=True)
     valid_loader = None
     if os.path.exists(args.valid_folder):
         valid_dataset = SpectrogramDataset(args.valid_folder)
@@ -157,11 +242,16 @@ def main(argv=None):
                             "scheduler": None}, f"CKPT/svs_{args.label}_400.pth")
             print(f"\n[Info] Epoch {ep}: learning rate manually changed to 5e-4!\n")
         loss_sum = torch.zeros((), device=device)
-        for mix, voc, _mix_phase, _voc_phase in train_loader:
-            mix, voc = mix.to(device, non_blocking=True), voc.to(device, non_blocking=True)
+        if resident is not None:
+            steps = resident.num_batches(per_rank_batch, world)
+            stream = resident.batches(per_rank_batch, True, rank, world, ep)
+        else:
+            steps = len(train_loader)
+            stream = ((m.to(device, non_blocking=True), v.to(device, non_blocking=True)) for m, v, _a, _b in train_loader)
+        for mix, voc in stream:
             l1 = model.train_step(mix, voc, loss_scale=ALPHA_L1, grad_sync=grad_sync)      # train.py:271-300, L1 terms
             loss_sum += ALPHA_L1 * l1                                                       # no host sync per step
-        avg_train_loss = float(loss_sum) / max(len(train_loader), 1)
+        avg_train_loss = float(loss_sum) / max(steps, 1)
         log_buffer.append(f"{avg_train_loss}\n")
 
         if valid_loader and (ep + 1) % args.val_interval == 0:             # train.py:317-363

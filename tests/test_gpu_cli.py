@@ -111,3 +111,35 @@ def test_streaming_end_to_end(report):
         want = so.to_wave(pred, phase)
         assert abs(np.abs(got[ch]).max() - 0.9) <= 1e-5
         assert report(f"streaming separation channel {ch} (interior)", np.abs(got[ch] - want)[1024:-1024].max(), 1e-4)
+
+
+def test_resident_training_set(tmp_path, report):
+    """Tiles cut on the GPU from the HBM-resident training set against the reference's __getitem__ rule (oracle), bit for
+    bit: long / exactly-128 / short songs, every start incl. the last valid one; then one epoch of batches."""
+    rng = np.random.default_rng(11)
+    root = tmp_path / "spec"
+    os.makedirs(root / "mixture"), os.makedirs(root / "vocal")
+    files = {}
+    for i, T in enumerate((300, 128, 50, 129)):
+        name = f"{i:04d}_song{i}_spec.npy"
+        mix, voc = rng.random((513, T), dtype=np.float32), rng.random((513, T), dtype=np.float32)
+        np.save(root / "mixture" / name, mix), np.save(root / "vocal" / name, voc)
+        files[i] = (mix, voc, T)
+    ds = svs_train.SpectrogramDataset(str(root), samples_per_song=3)
+    res = svs_train.ResidentSpectrograms(ds, torch.device("cuda"))
+    assert len(res) == 12
+    songs = [0, 0, 0, 1, 2, 3, 3]
+    starts = [0, 57, 172, 0, 0, 0, 1]
+    mix, voc = res.crop(songs, starts)
+    for b, (sidx, st) in enumerate(zip(songs, starts)):
+        wm, wv = to.crop_item(files[sidx][0], files[sidx][1], st)
+        assert np.array_equal(mix[b].cpu().numpy(), wm) and np.array_equal(voc[b].cpu().numpy(), wv), (sidx, st)
+    report("resident crop vs __getitem__ rule (bit-exact)", 0.0, 0.0)
+    s2, st2 = res.draw(range(12))
+    assert s2 == [i % 4 for i in range(12)] and all(0 <= st <= max(files[s][2] - 128, 0) for s, st in zip(s2, st2))
+    seen = 0
+    for m, v in res.batches(5, shuffle=True):
+        assert m.shape[1:] == (1, 512, 128) and m.shape == v.shape and m.is_cuda
+        seen += m.shape[0]
+    assert seen == 12 and res.num_batches(5) == 3
+

@@ -183,3 +183,30 @@ def test_config_constants():
     from svs_unet_pytorch_amd import config
     assert (config.WINDOW_SIZE, config.HOP_SIZE, config.SAMPLE_RATE, config.INPUT_LEN, config.SAMPLES_PER_SONG) == (1024, 768, 8192, 128, 64)
     assert [config.num2str(n) for n in (0, 7, 42, 999, 1000, 12345)] == ["0000", "0007", "0042", "0999", "1000", "12345"]
+
+
+def test_epoch_order_covers_all_items():
+    """DataLoader / DistributedSampler semantics of the resident training set (train.py:178-185 of the reference)."""
+    from svs_unet_pytorch_amd.train import epoch_order
+    n = 37
+    assert sorted(epoch_order(n, True)) == list(range(n))
+    assert epoch_order(n, False) == list(range(n))
+    for world in (2, 3, 8):
+        parts = [epoch_order(n, True, r, world, epoch=5) for r in range(world)]
+        assert len({len(p) for p in parts}) == 1 and len(parts[0]) == (n + world - 1) // world
+        assert set(sum(parts, [])) == set(range(n))                       # every item, some twice (wrap-around padding)
+        assert parts == [epoch_order(n, True, r, world, epoch=5) for r in range(world)]      # same permutation on every call
+        assert parts != [epoch_order(n, True, r, world, epoch=6) for r in range(world)]
+
+
+def test_crop_oracle_rule():
+    from oracle.tiling_oracle import crop_item
+    rng = np.random.default_rng(3)
+    for T, start in ((300, 0), (300, 172), (128, 0), (50, 0), (129, 1)):
+        mix, voc = rng.random((513, T), dtype=np.float32), rng.random((513, T), dtype=np.float32)
+        m, v = crop_item(mix, voc, start)
+        assert m.shape == v.shape == (1, 512, 128) and m.dtype == np.float32
+        w = min(T, 128)
+        assert np.array_equal(m[0, :, :w], mix[1:, start:start + w]) and np.array_equal(v[0, :, :w], voc[1:, start:start + w])
+        assert not m[0, :, w:].any() and not v[0, :, w:].any()
+
