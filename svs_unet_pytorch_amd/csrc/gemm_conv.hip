@@ -738,10 +738,11 @@ static ConvPlan plan_conv(int mode, long Mmax, int N, int nkt_min, bool narrow =
   // skip is exact per position, and 4x the tiles need a quarter of the K-splits (same-device sweep at B=64: 64x64
   // beats 128x128 on every such layer, by 20 % on the 8x2 parity layers).
   if (narrow && N % 64 == 0) { pl.cfg = 5; pl.BM = 64; pl.BN = 64; }
+  if (narrow && N == 128) { pl.cfg = 6; pl.BM = 64; pl.BN = 128; }     // (deconv2 forward -9 %, conv4 fwd / conv5 bwd-data -2 %)
   if (const char* e = getenv("SVS_CONV_CFG")) {      // sweeps only
-    static const int bm[6] = {128, 128, 256, 256, 32, 64}, bn[6] = {128, 64, 32, 16, 128, 64};
+    static const int bm[7] = {128, 128, 256, 256, 32, 64, 64}, bn[7] = {128, 64, 32, 16, 128, 64, 128};
     const int c = atoi(e);
-    if (c >= 0 && c < 6 && N % bn[c] == 0) { pl.cfg = c; pl.BM = bm[c]; pl.BN = bn[c]; }
+    if (c >= 0 && c < 7 && N % bn[c] == 0) { pl.cfg = c; pl.BM = bm[c]; pl.BN = bn[c]; }
   }
   pl.mtiles = (Mmax + pl.BM - 1) / pl.BM;
   pl.grid_y = (mode == MODE_PARITY) ? 4 : 1;
@@ -772,6 +773,7 @@ static int launch_conv_gemm(const ConvGemmArgs& a, const ConvPlan& pl, hipStream
       case 0: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 128, 128, 2, 2, true>), grid, block, 0, stream, a); break;
       case 1: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 128, 64, 2, 2, true>), grid, block, 0, stream, a); break;
       case 4: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 32, 128, 1, 4, true>), grid, block, 0, stream, a); break;
+      case 6: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 64, 128, 2, 2, true>), grid, block, 0, stream, a); break;
       default: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 64, 64, 2, 2, true>), grid, block, 0, stream, a); break;
     }
     SVS_CHECK_LAUNCH("conv_gemm");
@@ -820,7 +822,7 @@ static bool narrow_level(int mode, int B, int C, int Wo, int N) {
 
 // narrow levels: batch-innermost rows so that whole taps of an M-tile fall into the padding and are skipped
 static int use_tap_skip(int mode, int B, int C, int Wo, int N, int cfg) {
-  const bool can = N > 32 /* tap-outer K order */ && (C & (C - 1)) == 0 && (cfg == 0 || cfg == 1 || cfg == 4 || cfg == 5);
+  const bool can = N > 32 /* tap-outer K order */ && (C & (C - 1)) == 0 && (cfg == 0 || cfg == 1 || cfg == 4 || cfg == 5 || cfg == 6);
   int skip = can && B >= 16 && ((mode == MODE_GATHER) ? Wo : (Wo + 1) / 2) <= 8;
   if (const char* e = getenv("SVS_CONV_SKIP")) {     // sweeps and tests: 0 = never, 2 = whenever the kernel supports it
     const int f = atoi(e);
@@ -965,7 +967,7 @@ int svs_conv_gemm_describe(int mode, int B, int H, int W, int C, int Ho, int Wo,
   }
   if (use_parity_window(mode, B, H, W, C, N, ldx)) { snprintf(buf, n, "parity_window_kernel<%d, %d, %d>", C, C == 32 ? 32 : 64, N / 16); return 1; }
   if (direct) { snprintf(buf, n, "conv_direct_kernel<%d, 4, %d>", mode, N / 16); return 1; }
-  static const int wm[10] = {2, 2, 4, 4, 1, 2, 2, 4, 4, 4}, wn[10] = {2, 2, 1, 1, 4, 2, 2, 1, 1, 1};
+  static const int wm[10] = {2, 2, 4, 4, 1, 2, 2, 4, 4, 4}, wn[10] = {2, 2, 1, 1, 4, 2, 2, 1, 1, 1};     // (6 = 64x128, 2x2 waves)
   const ConvPlan pl = plan_conv(mode, Mmax, N, nkt_min, narrow_level(mode, B, C, Wo, N));
   snprintf(buf, n, "conv_gemm_kernel<%d, %d, %d, %d, %d, %s>", mode, pl.BM, pl.BN, wm[pl.cfg], wn[pl.cfg],
            use_tap_skip(mode, B, C, Wo, N, pl.cfg) ? "true" : "false");

@@ -18,8 +18,7 @@ from svs_unet_pytorch_amd import _lib  # noqa: E402
 
 CH = (1, 16, 32, 64, 128, 256, 512)
 DEC = ((512, 256), (512, 128), (256, 64), (128, 32), (64, 16))
-CFG = {0: (128, 128), 1: (128, 64), 2: (256, 32), 3: (256, 16), 4: (32, 128), 5: (64, 64), 6: (256, 128), 7: (512, 64), 8: (512, 32),
-       9: (512, 16)}
+CFG = {0: (128, 128), 1: (128, 64), 2: (256, 32), 3: (256, 16), 4: (32, 128), 5: (64, 64), 6: (64, 128)}
 
 
 def sizes(H=512, W=128):
