@@ -290,6 +290,28 @@ def test_production_kernels_at_batch_32(report, monkeypatch):
     assert report("B32 loss vs fp32 CPU oracle", abs(loss_fast - lo) / lo, 1e-5)
 
 
+def test_train_steps_are_bitwise_reproducible(report):
+    """Two streams, split-K slabs, batched reductions, no atomics: the same five steps (generated dropout masks, B = 32 so
+    that the production kernels run) must end in bit-identical parameters, Adam moments and BatchNorm buffers -- a race
+    between the main and the side stream, or an order-dependent reduction, would show up here."""
+    B = 32
+    mix_np, voc_np = synth.tiles(B, first_tile=2100)
+    mix, voc = torch.from_numpy(mix_np).to(DEV), torch.from_numpy(voc_np).to(DEV)
+
+    def run():
+        m = make_model(trained_stats=False).train()
+        losses = [m.train_step(mix, voc, loss_scale=166.66).item() for _ in range(5)]
+        torch.cuda.synchronize()
+        return losses, m._flat.clone(), m.optim._m.clone(), m.optim._v.clone(), m._bn_flat.clone()
+
+    a, b = run(), run()
+    assert a[0] == b[0], (a[0], b[0])
+    for x, y, name in zip(a[1:], b[1:], ("parameters", "Adam m", "Adam v", "BatchNorm buffers")):
+        assert torch.equal(x, y), name
+    assert all(np.isfinite(a[0])) and a[0][-1] < a[0][0]
+    report("five train steps twice: bit-identical state", 0.0, 0.0)
+
+
 def test_train_step_learns_and_checkpoint_roundtrip(tmp_path, report):
     B = 8
     mix_np, voc_np = synth.tiles(B, first_tile=500)
