@@ -272,16 +272,24 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(WgC1Args p) {
     const long b = tmp / p.Hs;
     const f32x4 s4 = *(const f32x4*)(p.s + chan_off(pix, p.lds, cg, G / 2, p.half));
     const float* img = p.l + b * p.Hl * p.Wl;
+    // The G lanes of a pixel need the same 25 window values.  Each loads only taps cg, cg + G, ... (the kernel was bound
+    // by the 25 x G-fold redundant loads: 2 TB/s) and the group shares them with lane permutes.
+    constexpr int NM = (25 + G - 1) / G;
+    float mine[NM];
 #pragma unroll
-    for (int kh = 0; kh < 5; ++kh) {
-      const int ih = 2 * i - 2 + kh;
+    for (int m = 0; m < NM; ++m) {
+      const int tap = cg + G * m;
+      const int kh = tap / 5, kw = tap - kh * 5;
+      const int ih = 2 * i - 2 + kh, iw = 2 * j - 2 + kw;
+      float lv = 0.f;
+      if (tap < 25 && (unsigned)ih < (unsigned)p.Hl && (unsigned)iw < (unsigned)p.Wl) lv = img[(long)ih * p.Wl + iw];
+      mine[m] = lv;
+    }
+    const int group = (t & 63) & ~(G - 1);
 #pragma unroll
-      for (int kw = 0; kw < 5; ++kw) {
-        const int iw = 2 * j - 2 + kw;
-        float lv = 0.f;
-        if ((unsigned)ih < (unsigned)p.Hl && (unsigned)iw < (unsigned)p.Wl) lv = img[(long)ih * p.Wl + iw];
-        acc[kh * 5 + kw] += s4 * lv;
-      }
+    for (int tap = 0; tap < 25; ++tap) {
+      const float lv = __shfl(mine[tap / G], group | (tap % G), 64);
+      acc[tap] += s4 * lv;
     }
   }
   // lanes with equal cg inside a wave, then the 4 waves through LDS (fixed order: reproducible)

@@ -19,7 +19,7 @@ from tools.ab_libs import timeit  # noqa: E402
 
 def load(path):
     h = ctypes.CDLL(os.path.abspath(path))
-    for name in ("svs_out_block_fwd",):
+    for name in ("svs_out_block_fwd", "svs_enc_block_bwd_weight", "svs_dec_block_bwd_weight", "svs_block_bwd_weight_workspace_bytes"):
         fn = getattr(h, name)
         fn.restype, fn.argtypes = _lib._SIGS[name]
     return h
@@ -49,6 +49,27 @@ def main():
         for i, r in enumerate(runs):
             best[i] = min(best[i], timeit(r, 20))
     mb = (x.numel() + ys[0].numel()) * 4 / 1e6
+    # the single-channel weight gradients: conv1 (S = dy 16 ch, L = mix) and deconv6 (S = x 32 ch, L = d_logit)
+    for tag, cs in (("conv1.bwd_weight", 16), ("deconv6.bwd_weight", 32)):
+        sm = torch.rand((B, H, W, cs), device="cuda") - 0.5
+        lg = torch.rand((B, 2 * H, 2 * W), device="cuda") - 0.5
+        dws = [torch.empty(cs * 25, device="cuda") for _ in libs]
+        wss = [torch.empty(int(L.svs_block_bwd_weight_workspace_bytes(B, H, W, cs, 1)) + 256, dtype=torch.uint8, device="cuda") for L in libs]
+        if cs == 16:
+            rs = [lambda L=L, dw=dw, ws=ws: L.svs_enc_block_bwd_weight(sm.data_ptr(), cs, B, H, W, cs, lg.data_ptr(), 1, 2 * H, 2 * W, 1, dw.data_ptr(),
+                                                                       None, ws.data_ptr(), ws.numel(), S()) for L, dw, ws in zip(libs, dws, wss)]
+        else:
+            rs = [lambda L=L, dw=dw, ws=ws: L.svs_dec_block_bwd_weight(sm.data_ptr(), cs, B, H, W, cs, lg.data_ptr(), 1, 2 * H, 2 * W, 1, dw.data_ptr(),
+                                                                       None, ws.data_ptr(), ws.numel(), S()) for L, dw, ws in zip(libs, dws, wss)]
+        for r in rs:
+            assert r() == 0
+        torch.cuda.synchronize()
+        bb = [1e9, 1e9]
+        for _ in range(5):
+            for i, r in enumerate(rs):
+                bb[i] = min(bb[i], timeit(r, 20))
+        rel = ((dws[0] - dws[1]).abs().max() / dws[0].abs().max()).item()
+        print(f"{tag:20s} A {bb[0] * 1e3:7.1f} us   B {bb[1] * 1e3:7.1f} us   reldiff {rel:.1e}")
     print(f"deconv6.fwd  A {best[0] * 1e3:7.1f} us ({mb / best[0] / 1e3:.2f} TB/s)   B {best[1] * 1e3:7.1f} us ({mb / best[1] / 1e3:.2f} TB/s)"
           f"   maxdiff {(ys[0] - ys[1]).abs().max().item():.1e}")
 
