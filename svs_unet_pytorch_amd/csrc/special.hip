@@ -314,6 +314,111 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(WgC1Args p) {
   for (int i = t; i < 25 * CS; i += 256) out[i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
 }
 
+// The same gradient on the MFMA: dw[cs][tap] = sum_pixels S[pixel][cs] * L[window(pixel, tap)] is a GEMM with M = CS,
+// N = 25 taps (two 16-column tiles, the last 7 columns unused) and K = pixels.  Each WAVE walks its own run of 4 x 16-pixel
+// tiles: the tile's S vectors go through a private LDS region (pixel-major, pitch LS, so that the transposed MFMA
+// A-operand read is conflict-free) and so does the 11 x 35 single-channel window; A = S^T (16 cs x 4 pixels), B = window
+// values gathered per (pixel, tap) with a per-lane tap offset.  No block barriers; the accumulators live across all tiles
+// of a wave and each wave writes one slab.  The VALU kernel above needs 25 x CS multiply-adds and, even with shared
+// loads, 25 lane permutes per pixel and lane; here a pixel costs CS/16 x 2 / 4 MFMAs.
+template <int CS>
+__global__ __launch_bounds__(256) void wgrad_c1_mfma_kernel(WgC1Args p, int ntiles, int tiles_per_wave) {
+  constexpr int TH = 4, TW = 16, MT = CS / 16;
+  constexpr int LS = (CS == 32) ? 48 : 16;           // pixel pitch: four pixels x 16 cs -> 64 different banks
+  constexpr int LH = 2 * TH + 3, LW = 2 * TW + 3, LWP = LW + 1;
+  constexpr int NSP = TH * TW * (CS / 4) / 64;       // b128 pieces of S per lane and tile
+  constexpr int NLP = (LH * LW + 63) / 64;           // window floats per lane and tile
+  __shared__ __attribute__((aligned(16))) float Ssm[4][TH * TW * LS];
+  __shared__ float Lsm[4][LH * LWP];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int lrow = lane & 15, q = lane >> 4;
+  float* const sS = Ssm[wave];
+  float* const sL = Lsm[wave];
+  const int tiles_w = (p.Ws + TW - 1) / TW, tiles_h = (p.Hs + TH - 1) / TH;
+  const int gw = blockIdx.x * 4 + wave;
+  const int tile_lo = gw * tiles_per_wave;
+  const int tile_hi = min(tile_lo + tiles_per_wave, ntiles);
+
+  f32x4 sreg[NSP];
+  float lreg[NLP];
+  auto fetch = [&](int tile) {
+    const int tw0 = (tile % tiles_w) * TW, th0 = ((tile / tiles_w) % tiles_h) * TH;
+    const long b = tile / (tiles_w * tiles_h);
+#pragma unroll
+    for (int r = 0; r < NSP; ++r) {
+      const int e = lane + 64 * r;
+      const int c4 = e % (CS / 4), px = e / (CS / 4);
+      const int sh = th0 + px / TW, sw = tw0 + px % TW;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (sh < p.Hs && sw < p.Ws) v = *(const f32x4*)(p.s + chan_off((b * p.Hs + sh) * p.Ws + sw, p.lds, c4, CS / 8, p.half));
+      sreg[r] = v;
+    }
+    const float* img = p.l + b * p.Hl * p.Wl;
+#pragma unroll
+    for (int r = 0; r < NLP; ++r) {
+      const int e = lane + 64 * r;
+      const int wr = e / LW, wc = e % LW;
+      const int ih = 2 * th0 - 2 + wr, iw = 2 * tw0 - 2 + wc;
+      float v = 0.f;
+      if (e < LH * LW && (unsigned)ih < (unsigned)p.Hl && (unsigned)iw < (unsigned)p.Wl) v = img[(long)ih * p.Wl + iw];
+      lreg[r] = v;
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int r = 0; r < NSP; ++r) {
+      const int e = lane + 64 * r;
+      *(f32x4*)(&sS[(e / (CS / 4)) * LS + (e % (CS / 4)) * 4]) = sreg[r];
+    }
+#pragma unroll
+    for (int r = 0; r < NLP; ++r) {
+      const int e = lane + 64 * r;
+      if (e < LH * LW) sL[(e / LW) * LWP + e % LW] = lreg[r];
+    }
+  };
+  f32x4 acc[MT][2];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) { acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[i][1] = acc[i][0]; }
+  // B operand: column lrow of tap tile nt is tap nt*16 + lrow (clamped: columns 25..31 are never stored); k = pixel q of
+  // the k-step -> window offset of (tap) + two columns per pixel
+  int boff[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int tap = min(nt * 16 + lrow, 24);
+    boff[nt] = (tap / 5) * LWP + tap % 5 + 2 * q;
+  }
+  if (tile_lo < tile_hi) fetch(tile_lo);
+  for (int tile = tile_lo; tile < tile_hi; ++tile) {
+    stage();                                            // (one wave: LDS operations execute in program order)
+    if (tile + 1 < tile_hi) fetch(tile + 1);
+#pragma unroll
+    for (int ks = 0; ks < TH * TW / 4; ++ks) {
+      const int sh = ks / 4, sg = ks % 4;              // pixel (sh, 4 sg + q)
+      float bv[2];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) bv[nt] = sL[boff[nt] + 2 * sh * LWP + 8 * sg];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const float a = sS[(sh * TW + sg * 4 + q) * LS + i * 16 + lrow];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[nt], acc[i][nt], 0, 0, 0);
+      }
+    }
+  }
+  // acc[i][nt][r]: row cs = 16 i + 4 q + r, column tap = 16 nt + lrow
+  float* out = p.slab + (long)gw * (25 * CS);
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int tap = nt * 16 + lrow;
+      if (tap < 25) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[(i * 16 + 4 * q + r) * 25 + tap] = acc[i][nt][r];
+      }
+    }
+}
+
 // out[g][i] = sum of slabs z in group g (contiguous chunks of `per` slabs); grid (ceil(n/256), groups)
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slab, int nslab, int per, long n,
                                                            float* __restrict__ out) {
@@ -343,7 +448,8 @@ static int wgrad_c1_blocks(long P) {
 }
 
 size_t svs_wgrad_c1_workspace(int B, int Hs, int Ws, int Cs) {
-  return (size_t)(wgrad_c1_blocks((long)B * Hs * Ws) + C1_GROUPS) * 25 * Cs * sizeof(float);
+  (void)B; (void)Hs; (void)Ws;
+  return (size_t)(1024 + C1_GROUPS) * 25 * Cs * sizeof(float);          // up to 1024 slabs (one per block or per wave)
 }
 
 int svs_wgrad_c1_run(const float* s, long lds, int B, int Hs, int Ws, int Cs, const float* l, int Hl, int Wl,
@@ -360,15 +466,26 @@ int svs_wgrad_c1_run(const float* s, long lds, int B, int Hs, int Ws, int Cs, co
     return SVS_ERR_WORKSPACE;
   }
   WgC1Args a{s, lds, B, Hs, Ws, l, Hl, Wl, (float*)ws, (P + nb - 1) / nb, half};
-  if (Cs == 16) hipLaunchKernelGGL(wgrad_c1_kernel<16>, dim3(nb), dim3(256), 0, stream, a);
+  int nslab = nb;
+  const int ntiles = B * ((Hs + 3) / 4) * ((Ws + 15) / 16);
+  if (ntiles >= 256 && !getenv("SVS_WGRAD_C1_VALU")) {          // MFMA kernel: one slab per wave, <= 1024 waves (workspace bound)
+    int waves = ntiles < 1024 ? ntiles : 1024;
+    waves = (waves + 3) / 4 * 4;
+    if (waves > 1024) waves = 1024;
+    const int tpw = (ntiles + waves - 1) / waves;
+    waves = ((ntiles + tpw - 1) / tpw + 3) / 4 * 4;             // every launched wave writes its slab (possibly all zeros)
+    nslab = waves;
+    if (Cs == 16) hipLaunchKernelGGL(wgrad_c1_mfma_kernel<16>, dim3(waves / 4), dim3(256), 0, stream, a, ntiles, tpw);
+    else hipLaunchKernelGGL(wgrad_c1_mfma_kernel<32>, dim3(waves / 4), dim3(256), 0, stream, a, ntiles, tpw);
+  } else if (Cs == 16) hipLaunchKernelGGL(wgrad_c1_kernel<16>, dim3(nb), dim3(256), 0, stream, a);
   else hipLaunchKernelGGL(wgrad_c1_kernel<32>, dim3(nb), dim3(256), 0, stream, a);
   SVS_CHECK_LAUNCH("wgrad_c1");
   const long n = 25L * Cs;
-  float* tmp = (float*)ws + (size_t)nb * n;
-  const int groups = nb < C1_GROUPS ? nb : C1_GROUPS;
-  const int per = (nb + groups - 1) / groups;
+  float* tmp = (float*)ws + (size_t)nslab * n;
+  const int groups = nslab < C1_GROUPS ? nslab : C1_GROUPS;
+  const int per = (nslab + groups - 1) / groups;
   const unsigned gx = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(gx, (unsigned)groups), dim3(256), 0, stream, (const float*)ws, nb, per, n, tmp);
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(gx, (unsigned)groups), dim3(256), 0, stream, (const float*)ws, nslab, per, n, tmp);
   SVS_CHECK_LAUNCH("reduce_slabs");
   hipLaunchKernelGGL(reduce_slabs_kernel, dim3(gx, 1), dim3(256), 0, stream, (const float*)tmp, groups, groups, n, dw);
   SVS_CHECK_LAUNCH("reduce_slabs");

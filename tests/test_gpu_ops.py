@@ -390,6 +390,41 @@ def test_single_channel_bwd(report):
     assert report("deconv6_bwd_data", relerr(nchw(dx), x.grad), 2e-5)
 
 
+@pytest.mark.parametrize("B,H,W", [(4, 128, 128), (4, 130, 126), (5, 96, 150)])
+def test_single_channel_wgrad_mfma(B, H, W, report):
+    """The MFMA form of the single-channel weight gradients (>= 256 tiles of 4 x 16 pixels), conv1 (16 channels) and deconv6
+    (32 channels), ragged tiles and odd large-grid sizes included; strided S view."""
+    Hs, Ws = (H + 1) // 2, (W + 1) // 2
+    x = rnd((B, 1, H, W), 90, 0, 1).double()
+    w = rnd((16, 1, 5, 5), 91, -0.2, 0.2).double().requires_grad_(True)
+    y = F.conv2d(x, w, None, stride=2, padding=2)
+    dy = rnd(tuple(y.shape), 92)
+    y.backward(dy.double())
+    dyd = torch.full((B, Hs, Ws, 20), 9.0, device=DEV)
+    dyd[..., :16] = nhwc(dy).to(DEV)
+    xd = x.float().to(DEV)
+    dw = torch.empty((16, 1, 5, 5), device=DEV)
+    ws = ws_tensor(L().svs_block_bwd_weight_workspace_bytes(B, Hs, Ws, 16, 1))
+    _lib.check(L().svs_enc_block_bwd_weight(dyd.data_ptr(), 20, B, Hs, Ws, 16, xd.data_ptr(), 1, H, W, 1, dw.data_ptr(), None,
+                                            ws.data_ptr(), ws.numel(), S()))
+    assert report(f"conv1 wgrad (MFMA) B{B} {H}x{W}", relerr(dw, w.grad), 2e-5)
+    C = 32
+    x = rnd((B, C, Hs, Ws), 93).double()
+    w = rnd((C, 1, 5, 5), 94, -0.2, 0.2).double().requires_grad_(True)
+    op = (H - (2 * Hs - 1), W - (2 * Ws - 1))
+    y = F.conv_transpose2d(x, w, None, stride=2, padding=2, output_padding=op)
+    dy = rnd(tuple(y.shape), 95)
+    y.backward(dy.double())
+    xd = torch.full((B, Hs, Ws, C + 4), 9.0, device=DEV)
+    xd[..., :C] = nhwc(x.float()).to(DEV)
+    dyd = dy.to(DEV)
+    dw = torch.empty((C, 1, 5, 5), device=DEV)
+    ws = ws_tensor(L().svs_block_bwd_weight_workspace_bytes(B, Hs, Ws, C, 1))
+    _lib.check(L().svs_dec_block_bwd_weight(xd.data_ptr(), C + 4, B, Hs, Ws, C, dyd.data_ptr(), 1, H, W, 1, dw.data_ptr(), None,
+                                            ws.data_ptr(), ws.numel(), S()))
+    assert report(f"deconv6 wgrad (MFMA) B{B} {H}x{W}", relerr(dw, w.grad), 2e-5)
+
+
 @pytest.mark.parametrize("B,H,W,C,slope,use_drop", [(4, 16, 8, 64, 0.2, False), (3, 8, 4, 256, 0.0, True), (2, 64, 32, 16, 0.2, False),
                                                      (2, 4, 2, 512, 0.0, True)])
 def test_bn_train_fwd_bwd(B, H, W, C, slope, use_drop, report):
