@@ -19,7 +19,7 @@ from tools.ab_libs import timeit  # noqa: E402
 
 def load(path):
     h = ctypes.CDLL(os.path.abspath(path))
-    for name in ("svs_out_block_fwd", "svs_enc_block_bwd_weight", "svs_dec_block_bwd_weight", "svs_block_bwd_weight_workspace_bytes"):
+    for name in ("svs_out_block_fwd", "svs_enc_block_fwd", "svs_dec_block_bwd_data", "svs_enc_block_bwd_weight", "svs_dec_block_bwd_weight", "svs_block_bwd_weight_workspace_bytes"):
         fn = getattr(h, name)
         fn.restype, fn.argtypes = _lib._SIGS[name]
     return h
@@ -69,6 +69,26 @@ def main():
             for i, r in enumerate(rs):
                 bb[i] = min(bb[i], timeit(r, 20))
         rel = ((dws[0] - dws[1]).abs().max() / dws[0].abs().max()).item()
+        print(f"{tag:20s} A {bb[0] * 1e3:7.1f} us   B {bb[1] * 1e3:7.1f} us   reldiff {rel:.1e}")
+    # the single-channel convolutions: conv1 forward (1 -> 16) and deconv6 backward-data (1 -> 32)
+    img = torch.rand((B, 2 * H, 2 * W), device="cuda")
+    for tag, n in (("conv1.fwd", 16), ("deconv6.bwd_data", 32)):
+        wt = (torch.rand((n, 25), device="cuda") - 0.5) * 0.2
+        outs = [torch.empty((B, H, W, n), device="cuda") for _ in libs]
+        if n == 16:
+            rs = [lambda L=L, o=o: L.svs_enc_block_fwd(img.data_ptr(), 1, B, 2 * H, 2 * W, 1, wt.data_ptr(), None, None, None, 0.0, o.data_ptr(),
+                                                       n, n, 0, None, 0, S()) for L, o in zip(libs, outs)]
+        else:
+            rs = [lambda L=L, o=o: L.svs_dec_block_bwd_data(img.data_ptr(), 1, B, 2 * H, 2 * W, 1, wt.data_ptr(), o.data_ptr(), n, H, W, n, 0,
+                                                            None, 0, S()) for L, o in zip(libs, outs)]
+        for r in rs:
+            assert r() == 0
+        torch.cuda.synchronize()
+        bb = [1e9, 1e9]
+        for _ in range(5):
+            for i, r in enumerate(rs):
+                bb[i] = min(bb[i], timeit(r, 20))
+        rel = ((outs[0] - outs[1]).abs().max() / outs[0].abs().max()).item()
         print(f"{tag:20s} A {bb[0] * 1e3:7.1f} us   B {bb[1] * 1e3:7.1f} us   reldiff {rel:.1e}")
     print(f"deconv6.fwd  A {best[0] * 1e3:7.1f} us ({mb / best[0] / 1e3:.2f} TB/s)   B {best[1] * 1e3:7.1f} us ({mb / best[1] / 1e3:.2f} TB/s)"
           f"   maxdiff {(ys[0] - ys[1]).abs().max().item():.1e}")
