@@ -199,7 +199,8 @@ def main():
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        from svs_unet_pytorch_amd.parallel import init_process_group
+        init_process_group(rank, world, dev)
 
     B = args.batch or (64 if args.mode == "train" else 16)
     H, W = 512, 128

@@ -54,3 +54,13 @@ def broadcast_parameters(model, src: int = 0, group=None):
     dist.broadcast(model._bn_flat, src=src, group=group)
     dist.broadcast(model._nbt_flat, src=src, group=group)
     model._param_epoch += 1
+
+
+def init_process_group(rank: int, world: int, device: torch.device):
+    """RCCL process group with its collectives on a HIGH-priority stream: the gradient exchange runs beside two saturated
+    compute streams (the backward's own and the library's weight-gradient stream, itself high priority) and must not wait
+    for free CUs behind them."""
+    opts = dist.ProcessGroupNCCL.Options()
+    opts.is_high_priority_stream = True
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device, pg_options=opts)
+

@@ -181,7 +181,8 @@ def main(argv=None):
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        from .parallel import init_process_group
+        init_process_group(rank, world, device)
 
     log_file = f"LOG/log_{args.label}.txt"
     best_weight = f"CKPT/svs_best_{args.label}.pth"
