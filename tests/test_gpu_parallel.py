@@ -1,0 +1,95 @@
+"""-m gpu: the data-parallel train step end to end with TWO ranks on the one GPU of the box (gloo carries the exchange,
+since RCCL refuses two ranks on one device; the driver's 8-GPU run uses RCCL through the same code).  Each rank runs the
+real `UNet.train_step(grad_sync=GradAllReduce(...))`: forward + loss, the three backward parts with an asynchronous
+all-reduce after each (issued from the auxiliary stream behind `svs_unet_train_bwd_sync`), Adam with 1/world folded in.
+The parent process emulates the same two steps in one process -- both shards' `fwd_bwd`, gradients summed, Adam with
+grad_scale 1/2 -- and the parameters must agree bit for bit; so must the two ranks with each other."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from svs_unet_pytorch_amd import synth
+from svs_unet_pytorch_amd.model import UNet
+
+pytestmark = pytest.mark.gpu
+B, STEPS, SCALE = 8, 2, 166.66
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _fresh_model():
+    m = UNet()
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in synth.closed_form_state(trained_stats=False).items()})
+    return m.to("cuda").train()
+
+
+def _shard(rank):
+    mix, voc = synth.tiles(B, first_tile=4000 + rank * B)
+    return torch.from_numpy(mix).to("cuda"), torch.from_numpy(voc).to("cuda")
+
+
+def _worker(rank, world, port, out):
+    import torch.distributed as dist
+    from svs_unet_pytorch_amd.parallel import GradAllReduce, broadcast_parameters
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model = _fresh_model()
+        broadcast_parameters(model, 0)
+        sync = GradAllReduce(model)
+        assert sync.overlap and model.rank == rank and model.optim.grad_scale == 0.5
+        mix, voc = _shard(rank)
+        losses = [model.train_step(mix, voc, loss_scale=SCALE, grad_sync=sync).item() for _ in range(STEPS)]
+        torch.cuda.synchronize()
+        out.put((rank, losses, model._flat.cpu().numpy(), model._bn_flat.cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_overlapped_step_matches_single_process(report):
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        rank, losses, flat, bn = out.get(timeout=600)
+        got[rank] = (losses, flat, bn)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert np.array_equal(got[0][1], got[1][1]), "ranks diverged"
+
+    # the same two steps in one process: rank r's model sees shard r (its own BatchNorm statistics and dropout stream)
+    models = [_fresh_model() for _ in range(2)]
+    shards = [_shard(r) for r in range(2)]
+    for r, m in enumerate(models):
+        m.rank = r
+        m.optim.grad_scale = 0.5
+    losses = [[], []]
+    for _ in range(STEPS):
+        for r, m in enumerate(models):
+            m.optim.zero_grad()
+            losses[r].append(m.fwd_bwd(*shards[r], loss_scale=SCALE).item())
+        total = models[0]._gflat + models[1]._gflat
+        for m in models:
+            m._gflat.copy_(total)
+            m.optim.step()
+    torch.cuda.synchronize()
+    for r in range(2):
+        assert got[r][0] == losses[r], (got[r][0], losses[r])
+        assert np.array_equal(got[r][1], models[r]._flat.cpu().numpy()), f"rank {r} parameters"
+        assert np.array_equal(got[r][2], models[r]._bn_flat.cpu().numpy()), f"rank {r} BatchNorm buffers"
+    report("two ranks (gloo) vs single-process emulation: parameters bit-identical", 0.0, 0.0)
