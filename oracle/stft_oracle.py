@@ -112,3 +112,30 @@ def specific_istft(magnitude: np.ndarray, phase: np.ndarray, n_fft: int = 1024, 
         ang = np.concatenate([np.zeros((1, phase.shape[-1])), phase[i, 0].astype(np.float64)], axis=0)
         out.append(istft(mag * np.exp(1j * ang), n_fft, hop))
     return np.stack(out)[:, None, :]
+
+
+def specific_istft_adjoint(d_wav: np.ndarray, phase: np.ndarray, n_fft: int = 1024, hop: int = 768) -> np.ndarray:
+    """Gradient of specific_istft with respect to `magnitude`: (B,1,hop*(T-1)) d(loss)/d(wav) -> (B,1,512,T) float64.
+    The map magnitude -> waveform is linear, so this is its transpose (what autograd does to train.py:33-60):
+    divide by the window envelope, re-frame with the window (transpose of overlap-add), transpose of irfft
+    (G[k] = c_k/N * rfft(frame)[k], c_k = 1 for DC / Nyquist whose imaginary parts irfft ignores, else 2), then
+    d|S| = Re(conj(e^{i*phase}) * G); the DC row that train.py:41-42 pads in is dropped again."""
+    d_wav = np.asarray(d_wav, dtype=np.float64)
+    b, t = d_wav.shape[0], phase.shape[-1]
+    w = hann_periodic(n_fft)
+    env = window_sumsquare(t, n_fft, hop)
+    ok = env > np.finfo(np.float32).tiny
+    ck = np.full(n_fft // 2 + 1, 2.0)
+    ck[0] = ck[-1] = 1.0
+    out = np.zeros((b, 1, n_fft // 2, t))
+    for i in range(b):
+        g = np.zeros(n_fft + hop * (t - 1))
+        g[n_fft // 2: n_fft // 2 + hop * (t - 1)] = d_wav[i, 0]
+        g[ok] /= env[ok]
+        frames = np.stack([g[j * hop: j * hop + n_fft] * w for j in range(t)], axis=1)
+        G = np.fft.rfft(frames, axis=0) * (ck / n_fft)[:, None]
+        ang = np.concatenate([np.zeros((1, t)), phase[i, 0].astype(np.float64)], axis=0)
+        dm = G.real * np.cos(ang) + G.imag * np.sin(ang)
+        dm[-1] = G.real[-1] * np.cos(ang[-1])                 # Nyquist: only the real part of S enters irfft
+        out[i, 0] = dm[1:]
+    return out

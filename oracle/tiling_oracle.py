@@ -56,12 +56,12 @@ def separate(mix_spec: np.ndarray, mask_fn, seg_len: int = 128, vocal_solo: bool
 
 
 def crop_item(mix_file, voc_file, start, seg_len=128):
-    """SpectrogramDataset.__getitem__ of the reference (train.py:86-143), magnitudes only, with the random start passed in
-    (the reference draws it with random.randint(0, T - seg_len), train.py:121; that module builds the auraloss criterion at
-    import, train.py:26, so it cannot be imported here and this restatement is pinned by reading only): rows 1.. of the (513, T) files, columns
-    [start, start + seg_len) when T > seg_len, else the whole song right-padded with zeros (train.py:129-135).
-    Returns mix, voc of shape (1, 512, seg_len) float32."""
-    import numpy as np
+    """SpectrogramDataset.__getitem__ of the reference (train.py:86-143), magnitudes, with the random start passed in
+    (the reference draws it with ONE random.randint(0, T - seg_len) per item, train.py:121, shared by all four
+    outputs): rows 1.. of the (513, T) files, columns [start, start + seg_len) when T > seg_len, else the whole song
+    right-padded with zeros (train.py:129-135).  Returns mix, voc of shape (1, 512, seg_len) float32.
+    PINNED: oracle/gen_golden_train.py runs the reference's train.py as a script and asserts that its
+    SpectrogramDataset returns exactly these arrays (tests/golden/dataset_items.npz holds the hashes)."""
     mix, voc = np.asarray(mix_file)[1:, :], np.asarray(voc_file)[1:, :]
     T = mix.shape[1]
     if T > seg_len:
@@ -71,3 +71,14 @@ def crop_item(mix_file, voc_file, start, seg_len=128):
         mix, voc = np.pad(mix, pad), np.pad(voc, pad)
     return mix[np.newaxis].astype(np.float32), voc[np.newaxis].astype(np.float32)
 
+
+def crop_phase(phase_file, start, seg_len=128):
+    """The phase half of the same item (train.py:103-112,124-135): np.angle of the complex64 unit-phasor file as
+    float32, DC row dropped, the SAME start, right zero-padding.  Returns (1, 512, seg_len) float32.  Pinned as above."""
+    ang = np.angle(np.asarray(phase_file)).astype(np.float32)[1:, :]
+    T = ang.shape[1]
+    if T > seg_len:
+        ang = ang[:, start:start + seg_len]
+    else:
+        ang = np.pad(ang, ((0, 0), (0, seg_len - T)))
+    return ang[np.newaxis].astype(np.float32)

@@ -75,6 +75,17 @@ def tiles(batch: int, height: int = 512, width: int = 128, first_tile: int = 0):
     return mix, voc
 
 
+def song(n: int, frames: int):
+    """Synthetic spectrogram files of song `n` as data.py writes them (data.py:107-109): (mix, voc) float32 (513, frames)
+    magnitudes with 0 <= voc <= mix <= 1, and (mix_phase, voc_phase) complex64 unit phasors."""
+    off = (300 + n) << 32
+    mix = uniform(SEED_MIX, 513 * frames, off).reshape(513, frames)
+    voc = (mix * uniform(SEED_VOC_RATIO, 513 * frames, off).reshape(513, frames)).astype(np.float32)
+    pm = (uniform(5, 513 * frames, off).reshape(513, frames).astype(np.float64) * 2 - 1) * np.pi
+    pv = (uniform(6, 513 * frames, off).reshape(513, frames).astype(np.float64) * 2 - 1) * np.pi
+    return mix, voc, np.exp(1j * pm).astype(np.complex64), np.exp(1j * pv).astype(np.complex64)
+
+
 def audio(n_samples: int, channel: int = 0) -> np.ndarray:
     """float32 samples in [-1, 1): the config-5 synthetic stream (seed 2)."""
     return uniform(SEED_AUDIO, n_samples, channel << 32) * np.float32(2.0) - np.float32(1.0)

@@ -593,3 +593,18 @@ def test_stft_istft(report):
     o2 = out.clone()
     _lib.check(L().svs_scale_by_inv(o2.data_ptr(), o2.numel(), pk.data_ptr(), 0.9, S()))
     assert report("peak normalise", (o2 - out / out.abs().max() * 0.9).abs().max().item(), 1e-6)
+
+
+def test_specific_istft_golden(golden, report):
+    """svs_istft (angle form) through data.specific_istft against the output of the reference's own specific_istft
+    (train.py:33-60, captured by oracle/gen_golden_train.py from the reference function object)."""
+    from svs_unet_pytorch_amd.data import specific_istft
+    g = golden("specific_istft.npz")
+    T = 128
+    mag = synth.uniform(3, 2 * 512 * T).reshape(2, 1, 512, T)
+    ang = (synth.uniform(4, 2 * 512 * T) * 2 * np.pi - np.pi).astype(np.float32).reshape(2, 1, 512, T)
+    got = specific_istft(torch.from_numpy(mag).to(DEV), torch.from_numpy(ang).to(DEV)).cpu().numpy()
+    want = g["wav"]
+    assert got.shape == want.shape == (2, 1, 97536)
+    e = np.abs(got - want)[..., 1024:-1024].max() / np.abs(want).max()
+    assert report("specific_istft vs reference function (interior)", e, 2e-5)

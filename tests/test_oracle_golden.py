@@ -151,3 +151,71 @@ def test_to_spec_normalises_by_mixture_max():
     assert spec_voc.shape == spec_mix.shape == ph.shape                              # data.py:97-98 length alignment
     w = so.to_wave(spec_voc, ph)
     assert abs(np.abs(w).max() - 0.9) <= 1e-6                                        # data.py:162-164
+
+
+# ------------------------------------------------------------------------------------------------
+# fixtures captured from the reference's own train.py run as a script (oracle/gen_golden_train.py)
+# ------------------------------------------------------------------------------------------------
+def _sha(a):
+    import hashlib
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8)
+
+
+def test_dataset_items_match_reference_dataset(golden):
+    """SpectrogramDataset.__getitem__ (train.py:86-143): the oracle's crop_item / crop_phase reproduce the reference's
+    four tensors bit for bit (sha256 of the float32 bytes) for random-start, exact-length, short and L+1 songs."""
+    import random
+    g = golden("dataset_items.npz")
+    lengths = [int(t) for t in g["lengths"]]
+    assert int(g["len"]) == len(lengths) * 64                                        # train.py:83-84
+    songs = {n: synth.song(n, T) for n, T in enumerate(lengths)}
+    for seed in g["seeds"]:
+        for idx in (0, 1, 2, 3, 5, 6):
+            n = idx % len(lengths)
+            T = lengths[n]
+            random.seed(int(seed) * 1000 + idx)
+            start = random.randint(0, T - 128) if T > 128 else 0                     # train.py:121: ONE draw per item
+            p = f"s{int(seed)}.i{idx}."
+            assert start == int(g[p + "start"])
+            mix, voc, pm, pv = songs[n]
+            m, v = to.crop_item(mix, voc, start)
+            assert m.shape == v.shape == (1, 512, 128) and m.dtype == np.float32
+            assert np.array_equal(_sha(m), g[p + "mix_sha"]) and np.array_equal(_sha(v), g[p + "voc_sha"])
+            assert np.array_equal(_sha(to.crop_phase(pm, start)), g[p + "mix_phase_sha"])
+            assert np.array_equal(_sha(to.crop_phase(pv, start)), g[p + "voc_phase_sha"])
+
+
+def test_specific_istft_oracle_matches_reference_function(golden):
+    """train.py:33-60 called on the reference's own function object: waveform (fp32) and d(sum w*wav)/d(mag) (fp64)."""
+    g = golden("specific_istft.npz")
+    T = 128
+    mag = synth.uniform(3, 2 * 512 * T).reshape(2, 1, 512, T)
+    ang = (synth.uniform(4, 2 * 512 * T) * 2 * np.pi - np.pi).astype(np.float32).reshape(2, 1, 512, T)
+    got = so.specific_istft(mag, ang)
+    want = g["wav"]
+    assert got.shape == want.shape == (2, 1, 97536)
+    assert np.abs(got - want)[..., 1024:-1024].max() <= 2e-6 * np.abs(want).max()
+    # adjoint of the oracle's linear map mag -> wav against the reference's autograd gradient
+    wgt = synth.uniform(8, 2 * 97536).reshape(2, 1, 97536).astype(np.float64) - 0.5
+    dmag = so.specific_istft_adjoint(wgt, ang)
+    f = dmag.reshape(-1)
+    step = max(f.size // 4096, 1)
+    scale = np.abs(g["dmag_sample"]).max()
+    assert np.abs(f[::step][:4096] - g["dmag_sample"]).max() <= 1e-6 * scale
+    assert np.abs(dmag[0, 0, :4, :] - g["dmag_tile0_rows"]).max() <= 1e-6 * scale
+
+
+def test_train_step_b64_oracle_fp32_within_reference_noise(golden):
+    """BASELINE configs[2] batch size: the fp32 oracle against the reference's own fp64 / fp32 runs at B = 64."""
+    g = golden("train_b64.npz")
+    names = list(g["param_names"])
+    B = 64
+    mix_np, voc_np = synth.tiles(B)
+    st = uo.to_torch_state(synth.closed_form_state(trained_stats=False))
+    masks = [torch.from_numpy(m) for m in synth.dropout_masks(B, seed=64, step=0)]
+    loss, grads = uo.train_step(st, uo.new_adam_state(st), torch.from_numpy(mix_np), torch.from_numpy(voc_np), dropout_masks=masks)
+    assert abs(loss - float(g["f64.loss"])) <= 1e-5 * float(g["f64.loss"])
+    gn64, gn32 = g["f64.grad_norm"], g["f32.grad_norm"]
+    for i, n in enumerate(names):
+        noise = max(abs(gn32[i] - gn64[i]), 1e-4 * gn64[i], 2e-6)
+        assert abs(grads[n].double().norm().item() - gn64[i]) <= 20 * noise, n
