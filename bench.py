@@ -269,9 +269,9 @@ def main():
                 # the dominant kernel ALONE (its fixed-order slab reduction is a separate kernel in the rocprofv3
                 # summary): same calls again with the reduction skipped, so that avg_launch_ms is comparable with
                 # the summary's average duration of that kernel
-                os.environ["SVS_SKIP_REDUCE"] = "1"
+                _lib.tuning("SKIP_REDUCE", 1)
                 alone = [c for c in time_gemm_calls(B, args.mode, only_kernel=dom)]
-                os.environ.pop("SVS_SKIP_REDUCE")
+                _lib.tuning("SKIP_REDUCE", -1)
                 ms, gf, cnt = sum(c[3] for c in alone), sum(c[4] for c in alone), len(alone)
                 gf_in_image = sum(c[4] * c[5] for c in alone)
                 ach = gf / ms            # GFLOP / ms = TFLOP/s

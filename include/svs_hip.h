@@ -5,7 +5,10 @@
  * of those calls (or a run of them) and is what a maintainer would bind with ctypes -- see
  * INTEGRATION.md for the stub.  Conventions:
  *   - every pointer is a DEVICE pointer owned by the caller (torch); the library never allocates
- *     caller-visible memory, never synchronises the stream and holds no mutable global state;
+ *     caller-visible memory and never synchronises the stream.  Library-owned state, all of it: (1) per device, ONE
+ *     high-priority side stream and a handful of events, created on first use by the svs_unet_train_* entry points
+ *     (the weight gradients of a backward pass run there, see svs_unet_train_bwd_sync); (2) the table of tuning
+ *     switches behind svs_tuning_set (filled from the environment once).  Everything else is stateless;
  *   - scratch space is passed in (void* ws, size_t ws_bytes); the matching *_workspace_bytes query
  *     says how much is needed; 16-byte alignment is required of every tensor pointer;
  *   - activations are fp32 NHWC "views": pointer to channel 0 of pixel 0 plus `ld`, the distance in
@@ -14,7 +17,13 @@
  *     and the reference's NCHW coincide, so the network input/output are the reference's tensors;
  *   - return value: 0 = OK, <0 = invalid argument / workspace too small, >0 = hipError_t;
  *     svs_last_error_string() returns a thread-local description of the last failure;
- *   - re-entrant across threads and streams (torch's autograd engine calls from its own thread).
+ *   - callable from any host thread and on any stream (torch's autograd engine calls from its own thread): the
+ *     per-block and whole-network eval entry points are fully re-entrant; the svs_unet_train_* entry points of one
+ *     DEVICE are serialised by a library mutex while they enqueue (they share that device's side stream), and a split
+ *     pass (svs_unet_train_fwd_loss, then svs_unet_train_bwd_part 0, 2, 3 or 0, 1) must be issued in order by one
+ *     caller at a time;
+ *   - the device is the one the `stream` argument belongs to; the caller makes it current (hipSetDevice /
+ *     torch.cuda.device) around the call.
  */
 #ifndef SVS_HIP_H
 #define SVS_HIP_H
@@ -36,6 +45,11 @@ extern "C" {
 
 int svs_version(void);
 const char* svs_last_error_string(void);
+/* Planner overrides for sweeps, A/B runs and tests -- never needed in production.  `name` is one of CONV_CFG,
+ * CONV_KSPLIT, CONV_WINDOW, CONV_SKIP, CONV_KORDER, CONV_DIRECT, SKIP_REDUCE, WGRAD_CFG, WGRAD_KSPLIT, WGRAD_SKIP,
+ * WGRAD_WINDOW, WGRAD_C1_VALU, SIDE_PRIORITY, TRAIN_UNFUSED, TRAIN_ONE_STREAM, or "*" for all; value -1 = planner
+ * default.  The table is initialised once from the environment (SVS_<NAME>); no call path reads the environment. */
+int svs_tuning_set(const char* name, long value);
 
 /* ---------------------------------------------------------------------------------------------
  * Synthetic data (bench / tests): the counter-based generator of svs_unet_pytorch_amd/synth.py.

@@ -29,6 +29,7 @@ _SIGS = {
     # name: (restype, [argtypes])
     "svs_version": (I, []),
     "svs_last_error_string": (C.c_char_p, []),
+    "svs_tuning_set": (I, [C.c_char_p, C.c_long]),
     "svs_fill_uniform": (I, [P, L, U32, U64, F, F, P]),
     "svs_fill_tiles": (I, [P, P, I, I, I, L, P]),
     "svs_crop_tiles": (I, [P, P, P, P, P, P, I, I, I, P, P, P]),
@@ -122,6 +123,12 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
-def stream_ptr():
+def stream_ptr(device=None):
+    """The current HIP stream of `device` (default: the current device) as an integer handle."""
     import torch
-    return torch.cuda.current_stream().cuda_stream
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def tuning(name: str, value: int = -1):
+    """Planner override for tests / sweeps (include/svs_hip.h: svs_tuning_set); value -1 restores the default."""
+    check(lib().svs_tuning_set(name.encode(), int(value)), "svs_tuning_set")

@@ -42,6 +42,19 @@ static inline bool svs_aligned16(const void* p) { return (((uintptr_t)p) & 15u) 
 static inline int svs_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline size_t svs_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// ---- tuning switches (sweeps, A/B runs and tests only) ------------------------------------------
+// Every planner override lives in ONE table that is filled from the environment (SVS_<NAME>) once, at the first
+// use, and can afterwards only be changed through svs_tuning_set() (include/svs_hip.h) -- no getenv() in any call
+// path.  -1 = not set: the planner decides.
+enum SvsTune {
+  SVS_TUNE_CONV_CFG, SVS_TUNE_CONV_KSPLIT, SVS_TUNE_CONV_WINDOW, SVS_TUNE_CONV_SKIP, SVS_TUNE_CONV_KORDER,
+  SVS_TUNE_CONV_DIRECT, SVS_TUNE_SKIP_REDUCE, SVS_TUNE_WGRAD_CFG, SVS_TUNE_WGRAD_KSPLIT, SVS_TUNE_WGRAD_SKIP,
+  SVS_TUNE_WGRAD_WINDOW, SVS_TUNE_WGRAD_C1_VALU, SVS_TUNE_SIDE_PRIORITY, SVS_TUNE_TRAIN_UNFUSED,
+  SVS_TUNE_TRAIN_ONE_STREAM, SVS_TUNE_COUNT
+};
+long svs_tune(int key);                       // -1 when unset
+static inline bool svs_tune_on(int key) { return svs_tune(key) >= 0; }
+
 // geometry of the 5x5 / stride 2 / pad 2 layers (reference model.py:48,79: kernel (5,5), stride (2,2), padding 2)
 static inline int svs_conv_out(int n) { return (n + 1) / 2; }  // floor((n+4-5)/2)+1
 

@@ -739,9 +739,9 @@ static ConvPlan plan_conv(int mode, long Mmax, int N, int nkt_min, bool narrow =
   // beats 128x128 on every such layer, by 20 % on the 8x2 parity layers).
   if (narrow && N % 64 == 0) { pl.cfg = 5; pl.BM = 64; pl.BN = 64; }
   if (narrow && N == 128) { pl.cfg = 6; pl.BM = 64; pl.BN = 128; }     // (deconv2 forward -9 %, conv4 fwd / conv5 bwd-data -2 %)
-  if (const char* e = getenv("SVS_CONV_CFG")) {      // sweeps only
+  if (svs_tune_on(SVS_TUNE_CONV_CFG)) {      // sweeps only
     static const int bm[7] = {128, 128, 256, 256, 32, 64, 64}, bn[7] = {128, 64, 32, 16, 128, 64, 128};
-    const int c = atoi(e);
+    const int c = (int)svs_tune(SVS_TUNE_CONV_CFG);
     if (c >= 0 && c < 7 && N % bn[c] == 0) { pl.cfg = c; pl.BM = bm[c]; pl.BN = bn[c]; }
   }
   pl.mtiles = (Mmax + pl.BM - 1) / pl.BM;
@@ -759,7 +759,7 @@ static ConvPlan plan_conv(int mode, long Mmax, int N, int nkt_min, bool narrow =
     if (ks > 64) ks = 64;
     if (ks < 1) ks = 1;
   }
-  if (const char* e = getenv("SVS_CONV_KSPLIT")) { int f = atoi(e); if (f >= 1 && f <= nkt_min) ks = f; }
+  if (svs_tune_on(SVS_TUNE_CONV_KSPLIT)) { int f = (int)svs_tune(SVS_TUNE_CONV_KSPLIT); if (f >= 1 && f <= nkt_min) ks = f; }
   pl.ksplit = ks;
   return pl;
 }
@@ -785,6 +785,7 @@ static int launch_conv_gemm(const ConvGemmArgs& a, const ConvPlan& pl, hipStream
     case 2: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 256, 32, 4, 1>), grid, block, 0, stream, a); break;
     case 3: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 256, 16, 4, 1>), grid, block, 0, stream, a); break;
     case 4: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 32, 128, 1, 4>), grid, block, 0, stream, a); break;
+    case 6: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 64, 128, 2, 2>), grid, block, 0, stream, a); break;
     default: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 64, 64, 2, 2>), grid, block, 0, stream, a); break;
   }
   SVS_CHECK_LAUNCH("conv_gemm");
@@ -808,15 +809,15 @@ static int use_parity_window(int mode, int B, int H, int W, int C, int N, long l
                         ((long)H * W * ldx) * 4 < (1L << 31);
   const bool fills_gpu = H >= 8 && W >= 16 && (long)B * ((H + 7) / 8) * ((W + 15) / 16) >= 128;   // (B=16 sweep: still ahead of the direct kernel at 128 blocks)
   int window = eligible && fills_gpu;
-  if (const char* e = getenv("SVS_CONV_WINDOW")) {     // sweeps and tests: 0 = never, 2 = whenever the shape is eligible
-    const int f = atoi(e);
+  if (svs_tune_on(SVS_TUNE_CONV_WINDOW)) {     // sweeps and tests: 0 = never, 2 = whenever the shape is eligible
+    const int f = (int)svs_tune(SVS_TUNE_CONV_WINDOW);
     window = (f == 0) ? 0 : (f == 2) ? eligible : window;
   }
   return window;
 }
 
 static bool narrow_level(int mode, int B, int C, int Wo, int N) {
-  if (getenv("SVS_CONV_SKIP") || getenv("SVS_CONV_KORDER")) return false;          // sweeps and tests keep the generic tiles
+  if (svs_tune_on(SVS_TUNE_CONV_SKIP) || svs_tune_on(SVS_TUNE_CONV_KORDER)) return false;          // sweeps and tests keep the generic tiles
   return N > 32 && (C & (C - 1)) == 0 && B >= 16 && ((mode == MODE_GATHER) ? Wo : (Wo + 1) / 2) <= 8;
 }
 
@@ -824,11 +825,11 @@ static bool narrow_level(int mode, int B, int C, int Wo, int N) {
 static int use_tap_skip(int mode, int B, int C, int Wo, int N, int cfg) {
   const bool can = N > 32 /* tap-outer K order */ && (C & (C - 1)) == 0 && (cfg == 0 || cfg == 1 || cfg == 4 || cfg == 5 || cfg == 6);
   int skip = can && B >= 16 && ((mode == MODE_GATHER) ? Wo : (Wo + 1) / 2) <= 8;
-  if (const char* e = getenv("SVS_CONV_SKIP")) {     // sweeps and tests: 0 = never, 2 = whenever the kernel supports it
-    const int f = atoi(e);
+  if (svs_tune_on(SVS_TUNE_CONV_SKIP)) {     // sweeps and tests: 0 = never, 2 = whenever the kernel supports it
+    const int f = (int)svs_tune(SVS_TUNE_CONV_SKIP);
     skip = (f == 0) ? 0 : (f == 2) ? can : skip;
   }
-  if (getenv("SVS_CONV_KORDER")) skip = 0;           // (the K-order sweep switch may select tap-inner order)
+  if (svs_tune_on(SVS_TUNE_CONV_KORDER)) skip = 0;           // (the K-order sweep switch may select tap-inner order)
   return skip;
 }
 
@@ -867,7 +868,7 @@ int svs_conv_gemm_run(int mode, const float* x, long ldx, int B, int H, int W, i
   a.cpt_shift = -1;
   if ((C & (C - 1)) == 0) { a.cpt_shift = 0; while ((16 << a.cpt_shift) < C) ++a.cpt_shift; }
   a.tap_inner = N <= 32;
-  if (const char* e = getenv("SVS_CONV_KORDER")) a.tap_inner = atoi(e) != 0;     // sweeps only
+  if (svs_tune_on(SVS_TUNE_CONV_KORDER)) a.tap_inner = svs_tune(SVS_TUNE_CONV_KORDER) != 0;     // sweeps only
   const long P = (long)B * Ho * Wo;
   const int window = use_parity_window(mode, B, H, W, C, N, ldx);
   if (window) pl.ksplit = 1;
@@ -887,7 +888,7 @@ int svs_conv_gemm_run(int mode, const float* x, long ldx, int B, int H, int W, i
     if (N == 16) direct = 1;                                    // 64 rows per wave (128 measured slower)
     else if (N == 32 && mode == MODE_PARITY && C >= 128) direct = 1;
   }
-  if (const char* e = getenv("SVS_CONV_DIRECT")) { const int f = atoi(e); if (f == 0 || (N <= 32 && Mmax >= 16384)) direct = f; }  // sweeps
+  if (svs_tune_on(SVS_TUNE_CONV_DIRECT)) { const int f = (int)svs_tune(SVS_TUNE_CONV_DIRECT); if (f == 0 || (N <= 32 && Mmax >= 16384)) direct = f; }  // sweeps
   const bool want_stats = stats && stats_nblk && !scale && !accumulate;
   if (window) {
     a.ksplit = 1; a.slab = nullptr;
@@ -926,7 +927,7 @@ int svs_conv_gemm_run(int mode, const float* x, long ldx, int B, int H, int W, i
   }
   rc = (mode == MODE_GATHER) ? launch_conv_gemm<MODE_GATHER>(a, pl, stream, skip) : launch_conv_gemm<MODE_PARITY>(a, pl, stream, skip);
   if (rc) return rc;
-  if (pl.ksplit > 1 && !getenv("SVS_SKIP_REDUCE")) {      // (the switch lets bench.py time the GEMM kernel alone)
+  if (pl.ksplit > 1 && !svs_tune_on(SVS_TUNE_SKIP_REDUCE)) {      // (the switch lets bench.py time the GEMM kernel alone)
     const long total4 = P * N / 4;
     int grid = (int)((total4 + 255) / 256);
     if (grid > 2048) grid = 2048;

@@ -408,8 +408,8 @@ static WgradPlan plan_wgrad(int B, int Hs, int Ws, int Cs, int Cl) {
   // 64-row tiles where the 128-row ones leave too few blocks per K-split (same-device sweep at B=64: the 8x2 level and
   // the 32-channel windows gain 4-8 %, everything else is neutral or loses)
   if (pl.cfg == 0 && ((long)B * Hs * Ws <= 1024 || Cl <= 32)) { pl.cfg = 1; pl.BM = 64; }
-  if (const char* e = getenv("SVS_WGRAD_CFG")) {     // sweeps only
-    const int c = atoi(e);
+  if (svs_tune_on(SVS_TUNE_WGRAD_CFG)) {     // sweeps only
+    const int c = (int)svs_tune(SVS_TUNE_WGRAD_CFG);
     if (c == 0 && Cs % 128 == 0) { pl.cfg = 0; pl.BM = 128; }
     if (c == 1 && Cs % 64 == 0) { pl.cfg = 1; pl.BM = 64; }
     if (c == 2 && Cs % 32 == 0) { pl.cfg = 2; pl.BM = 32; }
@@ -422,7 +422,7 @@ static WgradPlan plan_wgrad(int B, int Hs, int Ws, int Cs, int Cl) {
   if (ks > cap) ks = cap;
   if (ks > 512) ks = 512;
   if (ks < 1) ks = 1;
-  if (const char* e = getenv("SVS_WGRAD_KSPLIT")) { long f = atol(e); if (f >= 1 && f <= cap) ks = f; }
+  if (svs_tune_on(SVS_TUNE_WGRAD_KSPLIT)) { long f = svs_tune(SVS_TUNE_WGRAD_KSPLIT); if (f >= 1 && f <= cap) ks = f; }
   long pps = (P + ks - 1) / ks;
   pps = (pps + 15) / 16 * 16;
   ks = (P + pps - 1) / pps;
@@ -436,7 +436,7 @@ static int use_wgrad_skip(int B, int Hs, int Ws, int Cl, long lds, int cfg) {
   const bool can_skip = B >= 16 && (B & (B - 1)) == 0 && (Ws & (Ws - 1)) == 0 &&
                         (long)B * Hs * Ws * lds * 4 < (1L << 31);
   int skip = can_skip && Ws <= 8;
-  if (const char* e = getenv("SVS_WGRAD_SKIP")) { const int f = atoi(e); skip = (f == 0) ? 0 : (f == 2) ? can_skip : skip; }   // sweeps, tests
+  if (svs_tune_on(SVS_TUNE_WGRAD_SKIP)) { const int f = (int)svs_tune(SVS_TUNE_WGRAD_SKIP); skip = (f == 0) ? 0 : (f == 2) ? can_skip : skip; }   // sweeps, tests
   return skip;
 }
 
@@ -449,7 +449,7 @@ static WgWinPlan plan_wgrad_window(int B, int Hs, int Ws, int Cs, int Cl) {
   const bool eligible = (Cl == 16 || Cl == 32) && (Cs == 32 || Cs == 64 || Cs == 128);
   w.ntiles = B * ((Hs + 3) / 4) * ((Ws + 15) / 16);
   w.use = eligible && w.ntiles >= 1024;
-  if (const char* e = getenv("SVS_WGRAD_WINDOW")) { const int f = atoi(e); w.use = (f == 0) ? 0 : (f == 2) ? eligible : w.use; }   // sweeps, tests
+  if (svs_tune_on(SVS_TUNE_WGRAD_WINDOW)) { const int f = (int)svs_tune(SVS_TUNE_WGRAD_WINDOW); w.use = (f == 0) ? 0 : (f == 2) ? eligible : w.use; }   // sweeps, tests
   if (!w.use) return w;
   w.MT = (Cs % 64 == 0) ? 4 : 2;
   w.gy = (Cs / (16 * w.MT)) * (Cl / 16);
@@ -510,7 +510,7 @@ int svs_wgrad_gemm_run(const float* s, long lds, int B, int Hs, int Ws, int Cs, 
     else hipLaunchKernelGGL((wgrad_window_kernel<2>), dim3(wp.gx, wp.gy), dim3(256), 0, stream, wa);
     SVS_CHECK_LAUNCH("wgrad_window");
     pl.ksplit = wp.nslab;
-    if (getenv("SVS_SKIP_REDUCE")) return SVS_OK;
+    if (svs_tune_on(SVS_TUNE_SKIP_REDUCE)) return SVS_OK;
     return wgrad_reduce_run((const float*)ws, pl.ksplit, Cs, Cl, dw, (float*)ws + (size_t)pl.ksplit * Cs * 25 * Cl, stream);
   }
   WgradArgs a{};
@@ -535,7 +535,7 @@ int svs_wgrad_gemm_run(const float* s, long lds, int B, int Hs, int Ws, int Cs, 
     default: hipLaunchKernelGGL((wgrad_gemm_kernel<32, 128, 1, 4>), grid, dim3(256), 0, stream, a); break;
   }
   SVS_CHECK_LAUNCH("wgrad_gemm");
-  if (getenv("SVS_SKIP_REDUCE")) return SVS_OK;             // lets bench.py time the GEMM kernel alone
+  if (svs_tune_on(SVS_TUNE_SKIP_REDUCE)) return SVS_OK;             // lets bench.py time the GEMM kernel alone
   return wgrad_reduce_run((const float*)ws, pl.ksplit, Cs, Cl, dw, (float*)ws + (size_t)pl.ksplit * Cs * 25 * Cl, stream);
 }
 

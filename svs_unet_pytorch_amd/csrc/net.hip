@@ -14,6 +14,7 @@
 #include <math.h>
 #include <mutex>
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "internal.h"
@@ -29,6 +30,36 @@ void svs_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* svs_last_error_string(void) { return g_err; }
+
+// ---------------------------------------------------------------------------------------------
+// tuning table (common.h: SvsTune)
+// ---------------------------------------------------------------------------------------------
+static const char* const TUNE_NAMES[SVS_TUNE_COUNT] = {
+    "CONV_CFG", "CONV_KSPLIT", "CONV_WINDOW", "CONV_SKIP", "CONV_KORDER", "CONV_DIRECT", "SKIP_REDUCE", "WGRAD_CFG",
+    "WGRAD_KSPLIT", "WGRAD_SKIP", "WGRAD_WINDOW", "WGRAD_C1_VALU", "SIDE_PRIORITY", "TRAIN_UNFUSED", "TRAIN_ONE_STREAM"};
+static long g_tune[SVS_TUNE_COUNT];
+static std::once_flag g_tune_once;
+static void tune_load_env() {
+  for (int k = 0; k < SVS_TUNE_COUNT; ++k) {
+    char name[64];
+    snprintf(name, sizeof(name), "SVS_%s", TUNE_NAMES[k]);
+    const char* e = getenv(name);
+    g_tune[k] = e ? (*e ? atol(e) : 1) : -1;
+  }
+}
+long svs_tune(int key) {
+  std::call_once(g_tune_once, tune_load_env);
+  return (key >= 0 && key < SVS_TUNE_COUNT) ? g_tune[key] : -1;
+}
+extern "C" int svs_tuning_set(const char* name, long value) {
+  std::call_once(g_tune_once, tune_load_env);
+  SVS_REQUIRE(name, "svs_tuning_set: null name");
+  if (!strcmp(name, "*")) { for (int k = 0; k < SVS_TUNE_COUNT; ++k) g_tune[k] = value; return SVS_OK; }
+  for (int k = 0; k < SVS_TUNE_COUNT; ++k)
+    if (!strcmp(name, TUNE_NAMES[k])) { g_tune[k] = value; return SVS_OK; }
+  svs_set_error("svs_tuning_set: unknown switch '%s'", name);
+  return SVS_ERR_INVALID;
+}
 extern "C" int svs_version(void) { return SVS_ABI_VERSION; }
 
 // ---------------------------------------------------------------------------------------------
@@ -385,12 +416,15 @@ static TrainWs train_layout(const Geo& g, void* ws) {
 // machine while the main stream is in the bandwidth-bound BatchNorm passes and launch gaps, and its small reduction
 // kernels hide under the main stream's GEMMs.  Fork / join are events; d_raw is double-buffered so that the side
 // stream may trail the main one by a layer.  Results do not depend on the interleaving (no atomics anywhere).
-struct SideStream { hipStream_t s; hipEvent_t fork[4], done[4], sync; int nfork; };   // nfork: forks of the current backward pass
+struct SideStream { hipStream_t s; hipEvent_t fork[4], done[4], sync; int nfork; std::mutex mu; };   // nfork: forks of the current backward pass; mu: held while a training entry point enqueues
 static SideStream* g_side[64] = {};
 static std::mutex g_side_mutex;
-static SideStream* side_stream() {
+static SideStream* side_stream(hipStream_t of) {       // the side stream of the device `of` belongs to (legacy / null stream: the current device)
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  hipDevice_t sdev;
+  if (of && hipStreamGetDevice(of, &sdev) == hipSuccess) dev = (int)sdev;
+  else if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  if (dev < 0 || dev >= 64) return nullptr;
   std::lock_guard<std::mutex> lock(g_side_mutex);
   if (!g_side[dev]) {
     SideStream* sd = new SideStream();
@@ -399,7 +433,7 @@ static SideStream* side_stream() {
     int least = 0, greatest = 0;
     bool ok = hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess;
     int prio = greatest;
-    if (const char* e = getenv("SVS_SIDE_PRIORITY")) prio = atoi(e);                 // sweeps only
+    if (svs_tune_on(SVS_TUNE_SIDE_PRIORITY)) prio = (int)svs_tune(SVS_TUNE_SIDE_PRIORITY);   // sweeps only
     ok = ok && hipStreamCreateWithPriority(&sd->s, hipStreamNonBlocking, prio) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&sd->sync, hipEventDisableTiming) == hipSuccess;
     for (int i = 0; i < 4 && ok; ++i)
@@ -447,8 +481,10 @@ static int train_forward_impl(const ParamView& v, float* bn_buffers, int64_t* nb
                               const Geo& g, const TrainWs& t, float* mask, hipStream_t stream) {
   const int B = g.B;
   int rc;
-  const int fused_rows = getenv("SVS_TRAIN_UNFUSED") ? 0 : (int)(t.bnws_bytes / sizeof(float));     // capacity (floats) for fused BatchNorm partials; A/B switch
-  SideStream* sd = getenv("SVS_TRAIN_ONE_STREAM") ? nullptr : side_stream();          // A/B switch
+  const int fused_rows = svs_tune_on(SVS_TUNE_TRAIN_UNFUSED) ? 0 : (int)(t.bnws_bytes / sizeof(float));     // capacity (floats) for fused BatchNorm partials; A/B switch
+  SideStream* sd = svs_tune_on(SVS_TUNE_TRAIN_ONE_STREAM) ? nullptr : side_stream(stream);          // A/B switch
+  std::unique_lock<std::mutex> guard;
+  if (sd) guard = std::unique_lock<std::mutex>(sd->mu);
   // weight packings for this step (weights change every optimiser step)
   {
     SvsPackJobs jobs{};
@@ -532,8 +568,10 @@ static int train_backward_impl(const ParamView& v, float* grads, const float* mi
   int rc;
   auto G = [&](int idx) { return grads + svs_unet_param_offset(idx); };
   SvsSumJobs sums{};                         // bias-gradient reductions, run as one batched launch per half
-  const bool unfused = getenv("SVS_TRAIN_UNFUSED") != nullptr;     // A/B switch: one launch per reduction, as before
-  SideStream* sd = getenv("SVS_TRAIN_ONE_STREAM") ? nullptr : side_stream();   // A/B switch: everything on `stream`
+  const bool unfused = svs_tune_on(SVS_TUNE_TRAIN_UNFUSED);     // A/B switch: one launch per reduction, as before
+  SideStream* sd = svs_tune_on(SVS_TUNE_TRAIN_ONE_STREAM) ? nullptr : side_stream(stream);   // A/B switch: everything on `stream`
+  std::unique_lock<std::mutex> guard;
+  if (sd) guard = std::unique_lock<std::mutex>(sd->mu);
   const hipStream_t wstream = sd ? sd->s : stream;                  // where the weight gradients run
   float* const wscratch = sd ? t.scratch2 : t.scratch;
   const size_t wscratch_bytes = sd ? t.scratch2_bytes : t.scratch_bytes;
@@ -624,8 +662,9 @@ static int train_backward_impl(const ParamView& v, float* grads, const float* mi
 }
 
 extern "C" int svs_unet_train_bwd_sync(hipStream_t consumer) {
-  SideStream* sd = getenv("SVS_TRAIN_ONE_STREAM") ? nullptr : side_stream();
+  SideStream* sd = svs_tune_on(SVS_TUNE_TRAIN_ONE_STREAM) ? nullptr : side_stream(consumer);
   if (!sd) return SVS_OK;
+  std::lock_guard<std::mutex> guard(sd->mu);
   SVS_HIP(hipEventRecord(sd->sync, sd->s));
   SVS_HIP(hipStreamWaitEvent(consumer, sd->sync, 0));
   return SVS_OK;

@@ -29,6 +29,22 @@ import torch.nn as nn
 from . import _lib
 from ._lib import check, lib, ptr
 
+
+def _on_model_device(fn):
+    """Runs a UNet / FusedAdam method with the model's device current, so that every stream handed to the library
+    (and the library's own side stream) belongs to the device the parameters live on -- whatever device the caller
+    happens to have selected."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *a, **k):
+        dev = (self._model if hasattr(self, "_model") else self)._flat.device
+        if dev.type != "cuda" or torch.cuda.current_device() == dev.index:
+            return fn(self, *a, **k)
+        with torch.cuda.device(dev):
+            return fn(self, *a, **k)
+    return wrapped
+
 ENC_CHANNELS = (1, 16, 32, 64, 128, 256, 512)                                   # model.py:47-76
 DEC_IO = ((512, 256), (512, 128), (256, 64), (128, 32), (64, 16), (32, 1))      # model.py:79-109
 ALPHA_L1 = 166.66                                                                # train.py:24
@@ -95,6 +111,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._model._grads_clean = True     # the next backward overwrites the flat gradient buffer
 
     @torch.no_grad()
+    @_on_model_device
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         model = self._model
@@ -258,11 +275,12 @@ class UNet(nn.Module):
             self.load_state_dict(state["model_state_dict"], strict=False)
             if "optim" in state:
                 self.optim.load_state_dict(state["optim"])
+            self.dropout_step = int(state.get("dropout_step", self.optim._step))     # masks do not replay after a resume
         else:
             print("Pre-trained model {} is not exist...".format(path))
 
     def save(self, path):
-        state = {"model_state_dict": self.state_dict(), "optim": self.optim.state_dict()}
+        state = {"model_state_dict": self.state_dict(), "optim": self.optim.state_dict(), "dropout_step": self.dropout_step}
         for key in self.__dict__:
             if "loss_list" in key:
                 state[key] = getattr(self, key)
@@ -329,7 +347,11 @@ class UNet(nn.Module):
     # ==============================================================================
     def _eval_forward(self, mix):
         B, _, H, W = mix.shape
-        key = (self._flat._version, self._bn_flat._version, self._param_epoch)
+        # everything that can change the folded weights: in-place edits of any parameter / BatchNorm buffer (each
+        # parameter has its own version counter: p.data is re-pointed at the flat buffer), and `_param_epoch`, which
+        # every path that updates them through raw pointers bumps (training forwards, Adam, broadcasts, re-flattening)
+        key = (self._flat._version, self._bn_flat._version, self._param_epoch,
+               sum(p._version for p in self._param_list), sum(b._version for b in self._bn_views()))
         if self._prepared is None or self._prepared_key != key:
             if self._prepared is None:
                 self._prepared = torch.empty(int(lib().svs_unet_prepared_bytes()), dtype=torch.uint8, device=self._flat.device)
@@ -342,11 +364,17 @@ class UNet(nn.Module):
                                           _lib.stream_ptr()), "svs_unet_forward_eval")
         return mask
 
+    def _bn_views(self):
+        for bn in self._bn_list:
+            yield bn.running_mean
+            yield bn.running_var
+
     def _train_forward(self, mix):
         B, _, H, W = mix.shape
         ws = self._workspace("train", B, H, W)
         self._drop = self._drop_masks(B)
         self._generation += 1
+        self._param_epoch += 1          # the kernels update the BatchNorm running statistics through raw pointers
         mask = torch.empty_like(mix)
         check(lib().svs_unet_train_forward(ptr(self._flat), ptr(self._bn_flat), ptr(self._nbt_flat), ptr(mix),
                                            ptr(self._drop), B, H, W, ptr(mask), ptr(ws), ws.numel(), _lib.stream_ptr()),
@@ -362,6 +390,7 @@ class UNet(nn.Module):
         tmp = torch.empty_like(self._gflat)
         return tmp, tmp
 
+    @_on_model_device
     def _train_backward(self, mix, mask, d_mask):
         B, _, H, W = mix.shape
         ws = self._workspace("train", B, H, W)
@@ -372,6 +401,7 @@ class UNet(nn.Module):
             self._gflat.add_(tmp)
         self._grads_clean = False
 
+    @_on_model_device
     def forward(self, mix):
         """
             Generate the mask for the given mixture audio spectrogram
@@ -386,6 +416,7 @@ class UNet(nn.Module):
             return _TrainForward.apply(self._anchor, mix, self)
         return self._train_forward(mix)
 
+    @_on_model_device
     def fwd_bwd(self, mix, voc, loss_scale=1.0):
         """Fused training forward + L1 loss (train.py:274-283) + backward in one library call.
         Gradients of `loss_scale * loss` land in the flat gradient buffer; returns the unscaled loss
@@ -395,6 +426,7 @@ class UNet(nn.Module):
         ws = self._workspace("train", B, H, W)
         self._drop = self._drop_masks(B)
         self._generation += 1
+        self._param_epoch += 1
         target, tmp = self._grad_target()
         loss = torch.empty(1, dtype=torch.float32, device=mix.device)
         check(lib().svs_unet_train_fwd_bwd(ptr(self._flat), ptr(target), ptr(self._bn_flat), ptr(self._nbt_flat), ptr(mix),
@@ -405,6 +437,7 @@ class UNet(nn.Module):
         self._grads_clean = False
         return loss[0]
 
+    @_on_model_device
     def fwd_bwd_overlapped(self, mix, voc, loss_scale, grad_sync):
         """Same result as fwd_bwd, as four library calls so that the gradient exchange overlaps the backward:
         forward + loss; backward of the decoder half (its gradients occupy the tail of the flat buffer) followed
@@ -415,6 +448,7 @@ class UNet(nn.Module):
         ws = self._workspace("train", B, H, W)
         self._drop = self._drop_masks(B)
         self._generation += 1
+        self._param_epoch += 1
         self._attach_grads()
         assert self._grads_clean, "overlapped exchange needs zero_grad() first (it overwrites the flat gradient buffer)"
         loss = torch.empty(1, dtype=torch.float32, device=mix.device)

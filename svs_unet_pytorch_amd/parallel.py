@@ -3,10 +3,11 @@
 
 The reference is single-process (it has no distributed code at all), so the semantics are chosen here:
   * gradients: all-reduce (SUM, fp32) of the model's flat 9,823,313-element gradient buffer over RCCL/xGMI
-    (`backend="nccl"` is RCCL on ROCm) in TWO pieces that follow the backward pass: the decoder half (tensors
-    24..45, 5.45 M floats, produced first) is reduced on RCCL's stream while the encoder half (4.37 M floats)
-    is still being computed, then the encoder half.  xGMI is point-to-point, so fewer, larger messages beat many
-    small buckets; two is what the dependency structure of the backward pass offers.  The 1/world mean is folded
+    (`backend="nccl"` is RCCL on ROCm) in THREE pieces that follow the backward pass (`UNet.fwd_bwd_overlapped`):
+    the decoder blocks (tensors 24..45, 21.8 MB, produced first), the conv6 block (13.1 MB) and conv5..conv1
+    (4.4 MB); each piece is reduced on RCCL's stream while the next one is still being computed, so only the last,
+    smallest piece is exchanged after the backward has ended.  xGMI is point-to-point, so few large messages beat many
+    small buckets; three is what the dependency structure of the backward pass offers.  The 1/world mean is folded
     into the fused Adam kernel (`FusedAdam.grad_scale`), so there is no extra pass over the gradients;
   * BatchNorm: per-GPU batch statistics (what DistributedDataParallel over the reference would do);
     running statistics stay per rank and rank 0's are the ones checkpointed;
@@ -29,7 +30,7 @@ def shard_range(n_items: int, rank: int, world: int):
 
 class GradAllReduce:
     """`grad_sync` hook for `UNet.train_step`.  `overlap=True` (default): `reduce_async(slice)` is called
-    right after each half of the backward is enqueued; `overlap=False`: `__call__(flat)` after the backward."""
+    right after each piece of the backward is enqueued; `overlap=False`: `__call__(flat)` after the backward."""
 
     def __init__(self, model, group=None, overlap: bool = True):
         self.group = group

@@ -219,6 +219,7 @@ def main(argv=None):
         if "optim" in checkpoint:
             model.optim.load_state_dict(checkpoint["optim"])
         start_epoch = checkpoint.get("epoch", 0)
+        model.dropout_step = int(checkpoint.get("dropout_step", model.optim._step))      # Dropout2d masks continue, not replay
         for key in checkpoint:
             if key.startswith("loss_list"):
                 setattr(model, key, checkpoint[key])
@@ -280,7 +281,8 @@ def main(argv=None):
 
         if rank == 0:                                                      # train.py:369-382
             checkpoint = {"epoch": ep + 1, "model_state_dict": model.state_dict(), "optim": model.optim.state_dict(),
-                          "scheduler": scheduler.state_dict() if scheduler is not None else None}
+                          "scheduler": scheduler.state_dict() if scheduler is not None else None,
+                          "dropout_step": model.dropout_step}
             for key in model.__dict__:
                 if key.startswith("loss_list"):
                     checkpoint[key] = getattr(model, key)

@@ -34,3 +34,14 @@ def report():
             f.write(f"{name:60s} err={err:.3e} tol={tol:.1e} {'OK' if err <= tol else 'FAIL'}\n")
         return err <= tol
     return rec
+
+
+@pytest.fixture
+def tune():
+    """Planner overrides for one test (svs_tuning_set); every switch is back at its default afterwards."""
+    from svs_unet_pytorch_amd import _lib
+
+    def set_(name, value):
+        _lib.tuning(name, value)
+    yield set_
+    _lib.tuning("*", -1)

@@ -94,9 +94,9 @@ ENC_CASES = [
 
 @pytest.mark.parametrize("rows", ["bhw", "whb"])          # GEMM row order: planner default / batch-innermost + tap skipping forced
 @pytest.mark.parametrize("B,H,W,C,N", ENC_CASES)
-def test_enc_block_fwd(B, H, W, C, N, rows, report, monkeypatch):
+def test_enc_block_fwd(B, H, W, C, N, rows, report, tune):
     if rows == "whb":
-        monkeypatch.setenv("SVS_CONV_SKIP", "2")
+        tune("CONV_SKIP", 2)
     x = rnd((B, C, H, W), 10)
     w = rnd((N, C, 5, 5), 11, -0.1, 0.1)
     b = rnd((N,), 12)
@@ -159,9 +159,9 @@ DEC_CASES = [
 
 @pytest.mark.parametrize("rows", ["bhw", "whb"])
 @pytest.mark.parametrize("B,H,W,C,N,Ho,Wo", DEC_CASES)
-def test_dec_block_fwd(B, H, W, C, N, Ho, Wo, rows, report, monkeypatch):
+def test_dec_block_fwd(B, H, W, C, N, Ho, Wo, rows, report, tune):
     if rows == "whb":
-        monkeypatch.setenv("SVS_CONV_SKIP", "2")
+        tune("CONV_SKIP", 2)
     x = rnd((B, C, H, W), 30)
     w = rnd((C, N, 5, 5), 31, -0.1, 0.1)
     b = rnd((N,), 32)
@@ -202,8 +202,8 @@ WINDOW_CASES = [
 
 
 @pytest.mark.parametrize("B,H,W,C,N,Ho,Wo", WINDOW_CASES)
-def test_parity_window_kernel(B, H, W, C, N, Ho, Wo, report, monkeypatch):
-    monkeypatch.setenv("SVS_CONV_WINDOW", "2")
+def test_parity_window_kernel(B, H, W, C, N, Ho, Wo, report, tune):
+    tune("CONV_WINDOW", 2)
     buf = ctypes.create_string_buffer(128)
     L().svs_describe_plan(1, B, H, W, C, Ho, Wo, N, buf, 128)
     assert buf.value.decode().startswith("parity_window_kernel"), buf.value
@@ -303,19 +303,19 @@ def test_dec_block_bwd(B, H, W, C, N, Ho, Wo, report):
 
 @pytest.mark.parametrize("kind,B,H,W,C,N", [("enc", 16, 8, 4, 64, 128), ("enc", 32, 16, 16, 32, 128), ("dec", 16, 4, 2, 256, 128),
                                             ("dec", 16, 8, 8, 128, 64)])
-def test_wgrad_padding_skip(kind, B, H, W, C, N, report, monkeypatch):
+def test_wgrad_padding_skip(kind, B, H, W, C, N, report, tune):
     """Weight gradients with batch-innermost pixels and padding-only K-tiles skipped (forced on small shapes), against
     torch fp64; strided operand views."""
-    monkeypatch.setenv("SVS_WGRAD_SKIP", "2")
+    tune("WGRAD_SKIP", 2)
     _wgrad_case(kind, B, H, W, C, N, report, "wgrad skip")
 
 
 @pytest.mark.parametrize("kind,B,H,W,C,N", [("enc", 2, 16, 32, 16, 32), ("enc", 1, 18, 40, 32, 64), ("enc", 3, 8, 64, 16, 64),
                                             ("dec", 2, 8, 16, 64, 16), ("dec", 1, 6, 20, 128, 32), ("dec", 2, 4, 16, 32, 16),
                                             ("enc", 1, 34, 34, 32, 128)])
-def test_wgrad_window_kernel(kind, B, H, W, C, N, report, monkeypatch):
+def test_wgrad_window_kernel(kind, B, H, W, C, N, report, tune):
     """The LDS-window weight-gradient kernel (shallow layers), forced on small and ragged shapes."""
-    monkeypatch.setenv("SVS_WGRAD_WINDOW", "2")
+    tune("WGRAD_WINDOW", 2)
     buf = ctypes.create_string_buffer(128)
     if kind == "enc":
         L().svs_describe_plan(2, B, (H + 1) // 2, (W + 1) // 2, N, 0, 0, C, buf, 128)

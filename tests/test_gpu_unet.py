@@ -238,7 +238,7 @@ def test_train_vs_oracle_live_and_autograd_path(report):
     assert report("gradient accumulation", (twice[n] - 2 * auto[n]).norm().item() / auto[n].norm().item(), 1e-3)
 
 
-def test_production_kernels_at_batch_32(report, monkeypatch):
+def test_production_kernels_at_batch_32(report, tune):
     """The kernels the planner only picks at production batch sizes -- LDS-window parity kernels, batch-innermost row
     order with padding-tap skipping (conv and weight-gradient GEMMs), BatchNorm partials from the split-K epilogue,
     batched bias-gradient reduction, weight gradients on the side stream -- in one whole train step at B = 32:
@@ -266,9 +266,8 @@ def test_production_kernels_at_batch_32(report, monkeypatch):
         return loss.item(), m._gflat.clone(), m._bn_flat.clone(), _grads_by_name(m)
 
     loss_fast, g_fast, bn_fast, named = run()
-    for k, v in (("SVS_CONV_SKIP", "0"), ("SVS_WGRAD_SKIP", "0"), ("SVS_CONV_WINDOW", "0"), ("SVS_TRAIN_ONE_STREAM", "1"),
-                 ("SVS_TRAIN_UNFUSED", "1")):
-        monkeypatch.setenv(k, v)
+    for k, v in (("CONV_SKIP", 0), ("WGRAD_SKIP", 0), ("CONV_WINDOW", 0), ("TRAIN_ONE_STREAM", 1), ("TRAIN_UNFUSED", 1)):
+        tune(k, v)
     L.svs_describe_plan(0, B, 16, 4, 256, 8, 2, 512, buf, 128)
     assert buf.value.decode().endswith("false>"), buf.value
     loss_plain, g_plain, bn_plain, named_plain = run()
@@ -454,3 +453,38 @@ def test_train_step_b64_golden(golden, report):
         d = np.abs(f[::stp][:64].numpy() - g["f64.param_after." + n])
         assert report(f"train B=64 params after Adam {n} (max)", d.max(), 2.1e-3)
         assert report(f"train B=64 params after Adam {n} (share off)", float((d > 1e-6).mean()), 0.1)
+
+
+def test_eval_cache_follows_every_kind_of_weight_change(report):
+    """The folded eval weights (`_prepared`) must be rebuilt after ANY change of parameters or BatchNorm statistics:
+    an in-place edit of one parameter (each has its own version counter), a params-only load_state_dict(strict=False),
+    and a train-mode forward under no_grad (running statistics move through raw pointers, no optimizer step)."""
+    model = make_model().eval()
+    mix_np, _ = synth.tiles(2, first_tile=40)
+    x = torch.from_numpy(mix_np).to(DEV)
+
+    def oracle_mask():
+        sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+        with torch.no_grad():
+            return uo.forward(uo.to_torch_state(sd), torch.from_numpy(mix_np), training=False)
+
+    with torch.no_grad():
+        m0 = model(x).cpu()
+        # (1) in-place edit of one parameter
+        model.conv3[0].weight.mul_(1.5)
+        m1 = model(x).cpu()
+        assert report("eval after in-place param edit vs oracle", (m1 - oracle_mask()).abs().max().item(), 1e-4)
+        assert (m1 - m0).abs().max().item() > 1e-4
+        # (2) params-only partial load
+        model.load_state_dict({"deconv2.weight": model.deconv2.weight.detach().cpu() * 0.5}, strict=False)
+        m2 = model(x).cpu()
+        assert report("eval after strict=False load vs oracle", (m2 - oracle_mask()).abs().max().item(), 1e-4)
+        assert (m2 - m1).abs().max().item() > 1e-5
+        # (3) train-mode forward without an optimizer step: running statistics change
+        model.train()
+        model.set_dropout_masks([])
+        model(x)
+        model.eval()
+        m3 = model(x).cpu()
+        assert report("eval after train-mode forward vs oracle", (m3 - oracle_mask()).abs().max().item(), 1e-4)
+        assert (m3 - m2).abs().max().item() > 1e-5
