@@ -67,6 +67,9 @@ int svs_fill_tiles(float* mix, float* voc, int B, int H, int W, int64_t first_ti
 int svs_crop_tiles(const float* mix_songs, const float* voc_songs, const int64_t* offset, const int32_t* frames,
                    const int32_t* song, const int32_t* start, int B, int F, int seg, float* mix, float* voc,
                    hipStream_t stream);
+/* The phase half of the same items (train.py:103-112): angle = np.angle(unit phasor) = atan2(im, re) as float32; the
+ * resident angle buffers are then cropped with svs_crop_tiles exactly like the magnitudes (same shared start). */
+int svs_phase_angle(const float* phasor /* n complex64 */, float* angle, int64_t n, hipStream_t stream);
 int svs_dropout_mask(float* out, int B, int C, int layer, uint32_t seed, int step, int rank, hipStream_t stream);
 /* The five decoder masks of one step in one launch: out = [B*256 | B*128 | B*64 | B*32 | B*16] floats, each block
  * bit-identical to svs_dropout_mask(layer = 0..4) -- the layout svs_unet_train_* take as `drop`. */
@@ -236,6 +239,15 @@ int svs_unet_train_fwd_loss(const float* params, float* bn_buffers, int64_t* num
 int svs_unet_train_bwd_part(const float* params, float* grads, const float* mix, const float* drop, int B, int H, int W,
                             int part, void* ws, size_t ws_bytes, hipStream_t stream);
 int svs_unet_train_bwd_sync(hipStream_t consumer);
+/* The reference's FULL objective (train.py:274-296): alpha_l1 * L1 terms + alpha_mr * MultiResolutionSTFTLoss(
+ * specific_istft(mask * mix, mix_phase), specific_istft(voc, voc_phase)) -- forward, both losses, d(total)/d(logit).
+ * mix_phase / voc_phase: angles (B,1,512,W) (train.py:103-112).  Needs H = 512, W >= 2.  losses[0] = L1 part, losses[1] =
+ * MR part, both unscaled.  Follow with svs_unet_train_bwd_part (part 4 = whole backward; or the split forms). */
+size_t svs_unet_train_mr_workspace_bytes(int B, int W, int hop);
+int svs_unet_train_fwd_loss_mr(const float* params, float* bn_buffers, int64_t* num_batches_tracked, const float* mix,
+                               const float* voc, const float* mix_phase, const float* voc_phase, const float* drop, int B, int H,
+                               int W, int hop, float alpha_l1, float alpha_mr, float* mask, float* losses, void* ws, size_t ws_bytes,
+                               void* mr_ws, size_t mr_ws_bytes, hipStream_t stream);
 int64_t svs_unet_ws_offset(const char* name, int B, int H, int W, int training);  /* bytes, <0 unknown */
 
 /* ---------------------------------------------------------------------------------------------
@@ -252,8 +264,45 @@ int svs_stft_fwd(const float* y, int64_t n_samples, int n_fft, int hop, float* m
 size_t svs_istft_workspace_bytes(int n_fft, int hop, int frames);
 int svs_istft(const float* mag, const float* phase, int phase_is_angle, int n_fft, int hop, int frames,
               float* y, void* ws, size_t ws_bytes, hipStream_t stream);
+/* Batched / tiled forms (what the streaming path and the training loss use; the two calls above are the 1-channel,
+ * (513, frames)-file special case).  A spectrogram is addressed as f-major tiles of `seg` frames and `rows` rows whose
+ * first row is bin `first_bin` (0 or 1; rows == 513 - first_bin):
+ *     element (channel c, bin k, frame t) = base[c * chan_stride + ((t / seg) * rows + (k - first_bin)) * seg + t % seg]
+ * -> a (513, T) file is seg = T, rows = 513, first_bin = 0 (data.py:107); the network's input tiles (n, 1, 512, 128)
+ * with the DC row dropped (inference.py:68,84; train.py:109-127) are seg = 128, rows = 512, first_bin = 1, so the
+ * forward transform writes network tiles and the inverse reads them with no repacking pass.
+ * svs_stft_tiles: y (channels, n_samples) -> mag; frames t >= 1 + n_samples / hop up to frames_alloc are written as
+ *   zeros (tile padding, inference.py:90-92).  phase_mode 0: none; 1: frame-major unit phasors [c][t][513] (re, im) --
+ *   the streaming form, read back by svs_istft_tiles; 2: f-major (513, T) phasors per channel (the .npy form).
+ *   absmax_partial (optional): channels * svs_stft_groups(frames_alloc) per-block maxima of mag (reduce with svs_max). */
+int svs_stft_tiles(const float* y, int64_t n_samples, int channels, int n_fft, int hop, float* mag, int64_t chan_stride,
+                   int seg, int rows, int first_bin, int frames_alloc, float* phase, int phase_mode,
+                   float* absmax_partial, hipStream_t stream);
+int svs_stft_groups(int frames_alloc);
+/* svs_istft_tiles: y (channels, hop * (frames - 1)) = istft(mag [* mask or * (1 - mask)] * phase).  mask (optional, same
+ *   layout as mag) fuses inference.py:100-107.  phase_mode 1: frame-major phasors; 3: angles in the layout of mag
+ *   (train.py:33-60, `specific_istft`: the DC row that train.py:41-42 pads back is the absent first_bin row).
+ *   n_fft / 2 <= hop <= n_fft.  absmax_partial (optional): channels * svs_istft_groups(hop, frames) maxima of |y|. */
+int svs_istft_tiles(const float* mag, int64_t chan_stride, int seg, int rows, int first_bin, const float* mask, int invert,
+                    const float* phase, int phase_mode, int channels, int n_fft, int hop, int frames, float* y,
+                    float* absmax_partial, hipStream_t stream);
+int svs_istft_groups(int hop, int frames);
+/* (rows, cols) complex64 -> (cols, rows): f-major phasor files <-> the frame-major form */
+int svs_transpose_c64(const float* in, float* out, int rows, int cols, hipStream_t stream);
+/* Backward of `specific_istft` (train.py:33-60) fused with the chain rule of |S| = mask * mix (train.py:275,288):
+ *   d_logit[b,f,t] += alpha * dL/d|S|[b,f,t] * mix * mask * (1 - mask);   d_wav (B, hop*(frames-1)); the rest (B,1,512,frames) */
+int svs_istft_bwd_mask(const float* d_wav, const float* angle, const float* mix, const float* mask, float* d_logit,
+                       float alpha, int B, int n_fft, int hop, int frames, hipStream_t stream);
+/* Multi-resolution STFT loss of train.py:24-26,287-296 (auraloss.freq.MultiResolutionSTFTLoss with the reference's
+ * arguments; restated from its published definition -- csrc/mrstft.hip).  x = predicted, y = target waveform, (B, L):
+ *   loss[0] = MR-STFT(x, y);  d_x (optional) = grad_scale * d loss / d x. */
+size_t svs_mrstft_workspace_bytes(int B, int64_t L);
+int svs_mrstft_loss_fwd_bwd(const float* x, const float* y, int B, int64_t L, float grad_scale, float* loss, float* d_x,
+                            void* ws, size_t ws_bytes, hipStream_t stream);
 /* data.py:84-85,105 (divide by the mixture's maximum) and data.py:162-164 (peak-normalise to 0.9). */
 int svs_absmax(const float* x, int64_t n, float* out /*device scalar*/, void* ws, size_t ws_bytes, hipStream_t stream);
+/* out[0] = max(x[0..n)) for x >= 0 (the per-block partials of svs_stft_tiles / svs_istft_tiles) */
+int svs_max(const float* x, int64_t n, float* out, hipStream_t stream);
 int svs_scale_by_inv(float* x, int64_t n, const float* denom /*device scalar; 0 -> 1*/, float numer, hipStream_t stream);
 
 #ifdef __cplusplus

@@ -33,6 +33,7 @@ _SIGS = {
     "svs_fill_uniform": (I, [P, L, U32, U64, F, F, P]),
     "svs_fill_tiles": (I, [P, P, I, I, I, L, P]),
     "svs_crop_tiles": (I, [P, P, P, P, P, P, I, I, I, P, P, P]),
+    "svs_phase_angle": (I, [P, P, L, P]),
     "svs_dropout_mask": (I, [P, I, I, I, U32, I, I, P]),
     "svs_dropout_masks_all": (I, [P, I, U32, I, I, P]),
     "svs_pack_weight_gather": (I, [P, P, I, I, P]),
@@ -71,12 +72,23 @@ _SIGS = {
     "svs_unet_train_fwd_loss": (I, [P, P, P, P, P, P, I, I, I, F, P, P, P, Z, P]),
     "svs_unet_train_bwd_part": (I, [P, P, P, P, I, I, I, I, P, Z, P]),
     "svs_unet_train_bwd_sync": (I, [P]),
+    "svs_unet_train_mr_workspace_bytes": (Z, [I, I, I]),
+    "svs_unet_train_fwd_loss_mr": (I, [P, P, P, P, P, P, P, P, I, I, I, I, F, F, P, P, P, Z, P, Z, P]),
     "svs_unet_ws_offset": (L, [C.c_char_p, I, I, I, I]),
     "svs_stft_frames": (I, [L, I]),
     "svs_stft_fwd": (I, [P, L, I, I, P, P, P]),
     "svs_istft_workspace_bytes": (Z, [I, I, I]),
     "svs_istft": (I, [P, P, I, I, I, I, P, P, Z, P]),
+    "svs_stft_tiles": (I, [P, L, I, I, I, P, L, I, I, I, I, P, I, P, P]),
+    "svs_stft_groups": (I, [I]),
+    "svs_istft_tiles": (I, [P, L, I, I, I, P, I, P, I, I, I, I, I, P, P, P]),
+    "svs_istft_groups": (I, [I, I]),
+    "svs_transpose_c64": (I, [P, P, I, I, P]),
+    "svs_istft_bwd_mask": (I, [P, P, P, P, P, F, I, I, I, I, P]),
+    "svs_mrstft_workspace_bytes": (Z, [I, L]),
+    "svs_mrstft_loss_fwd_bwd": (I, [P, P, I, L, F, P, P, P, Z, P]),
     "svs_absmax": (I, [P, L, P, P, Z, P]),
+    "svs_max": (I, [P, L, P, P]),
     "svs_scale_by_inv": (I, [P, L, P, F, P]),
 }
 

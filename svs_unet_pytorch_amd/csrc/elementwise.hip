@@ -462,6 +462,13 @@ extern "C" int svs_absmax(const float* x, int64_t n, float* out, void* ws, size_
   return SVS_OK;
 }
 
+extern "C" int svs_max(const float* x, int64_t n, float* out, hipStream_t stream) {
+  SVS_REQUIRE(x && out && n > 0 && n < (1L << 31), "svs_max: bad arguments");
+  hipLaunchKernelGGL(max_partials_kernel, dim3(1), dim3(64), 0, stream, x, (int)n, out);
+  SVS_CHECK_LAUNCH("max_partials");
+  return SVS_OK;
+}
+
 __global__ __launch_bounds__(256) void scale_by_inv_kernel(float* x, long n, const float* denom, float numer) {
   float d = denom[0];
   if (d == 0.f) d = 1.f;
@@ -719,6 +726,17 @@ __global__ __launch_bounds__(256) void crop_tiles_kernel(const float* __restrict
     *(f32x4*)(mix + row * seg + 4 * t4) = m;
     *(f32x4*)(voc + row * seg + 4 * t4) = v;
   }
+}
+
+// np.angle of the unit-phasor files (train.py:103-104): angle[i] = atan2(im, re), float32
+__global__ __launch_bounds__(256) void phase_angle_kernel(const float2* __restrict__ z, float* __restrict__ out, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = atan2f(z[i].y, z[i].x);
+}
+extern "C" int svs_phase_angle(const float* phasor, float* angle, int64_t n, hipStream_t stream) {
+  SVS_REQUIRE(phasor && angle && n > 0 && (((uintptr_t)phasor) & 7u) == 0, "svs_phase_angle: bad arguments");
+  hipLaunchKernelGGL(phase_angle_kernel, dim3(grid_for(n)), dim3(256), 0, stream, (const float2*)phasor, angle, (long)n);
+  SVS_CHECK_LAUNCH("phase_angle");
+  return SVS_OK;
 }
 
 extern "C" int svs_crop_tiles(const float* mix_songs, const float* voc_songs, const int64_t* offset, const int32_t* frames,

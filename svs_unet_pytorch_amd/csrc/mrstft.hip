@@ -1,0 +1,311 @@
+// Multi-resolution STFT loss on the GPU (gfx950): forward value and gradient with respect to the predicted waveform.
+//
+// The reference adds `alpha_MR * auraloss.freq.MultiResolutionSTFTLoss(sample_rate=SAMPLE_RATE, device=device)(pred_wav,
+// target_wav)` to the L1 terms (train.py:24-26,287-296).  auraloss 0.4.0 (uv.lock:90-91) is NOT vendored and not
+// installable here, so this file restates its published definition for the constructor arguments the reference passes
+// (everything else at its default) -- PARITY UNPINNED against auraloss itself; pinned against oracle/mrstft_oracle.py,
+// which states the same definition on torch.stft:
+//   three resolutions (n_fft, hop, win_length) = (1024, 120, 600), (2048, 240, 1200), (512, 50, 240); per resolution
+//   X = torch.stft(x, n_fft, hop, win_length, hann_window(win_length), center=True, pad_mode="reflect"),
+//   |X| = sqrt(clamp(re^2 + im^2, min=1e-8));  loss = ||Y| - |X||_F / ||Y||_F  +  mean |log|X| - log|Y||   (w_sc = w_log_mag = 1);
+//   result = mean over the three resolutions.
+//
+// Kernels (one template per n_fft, fft_wave.h transforms, 512-thread blocks = 8 independent waves):
+//   mr_sums_kernel  one wave per frame position: the predicted and the target frame share ONE complex FFT (x in the
+//                   real part, y in the imaginary part); per-block partial sums of (|Y|-|X|)^2, |Y|^2, |log|X|-log|Y||.
+//   mr_finalize     fixed-order double-precision sums -> loss value and the two gradient coefficients per resolution.
+//   mr_grad_kernel  recomputes the spectra (cheaper than storing 12 bytes per bin), forms dL/dX, and brings TWO frames
+//                   back with one inverse FFT (Hermitian-extended spectra of frames t, t+1 in the real / imaginary part);
+//                   the windowed frame gradients go to a frame buffer.
+//   mr_ola_kernel   gathers, per output sample, the contributions of every frame (and of the two reflect-padding
+//                   mirrors) in a fixed order -- no atomics, bitwise reproducible.
+// Bound: HBM + VALU (FFT); algorithmic FLOPs ~ 2.5 * 5 N log2 N per frame position.
+#include "internal.h"
+#include "fft_wave.h"
+
+#define MR_NRES 3
+static const int MR_NFFT[MR_NRES] = {1024, 2048, 512};
+static const int MR_HOP[MR_NRES] = {120, 240, 50};
+static const int MR_WIN[MR_NRES] = {600, 1200, 240};
+#define MR_EPS 1e-8f
+
+// waves (= independent transforms) per block: the LDS of eight 2048-point buffers would exceed 160 KB
+template <int N> struct MrCfg { static constexpr int WAVES = (N == 2048) ? 4 : 8; };
+static int mr_waves(int n) { return n == 2048 ? 4 : 8; }
+
+struct MrArgs {
+  const float* x; const float* y; int B; long L;     // predicted / target waveforms (B, L)
+  int hop, win, F;                                   // this resolution: hop, window length, frames = 1 + L / hop
+  float* partial;                                    // [B * gridDim.x][3]
+  const float* coef;                                 // [2]: SC and log-magnitude gradient coefficients (device)
+  float* frames;                                     // [B][F][N] windowed frame gradients
+};
+
+template <int N>
+__device__ __forceinline__ void mr_window(float* wfull, int win, int tid, int nthreads) {
+  const int off = (N - win) / 2;                     // torch.stft centres a short window inside n_fft
+  for (int m = tid; m < N; m += nthreads) {
+    const int j = m - off;
+    wfull[m] = (j >= 0 && j < win) ? 0.5f - 0.5f * cospif(2.0f * (float)j / (float)win) : 0.f;
+  }
+}
+__device__ __forceinline__ long mr_reflect(long p, long L) { return p < 0 ? -p : (p >= L ? 2 * (L - 1) - p : p); }
+
+// frame t of x (real part) and y (imaginary part), windowed, into the wave's buffer
+template <int N>
+__device__ __forceinline__ void mr_fill(float2* buf, const float* wfull, const MrArgs& p, int b, int t, int lane) {
+#pragma unroll 4
+  for (int r = 0; r < N / 64; ++r) {
+    const int m = lane + 64 * r;
+    float2 v = float2{0.f, 0.f};
+    if (t < p.F) {
+      const long s = mr_reflect((long)t * p.hop + m - N / 2, p.L);
+      const float w = wfull[m];
+      v = float2{p.x[(long)b * p.L + s] * w, p.y[(long)b * p.L + s] * w};
+    }
+    buf[fft_pad(m)] = v;
+  }
+}
+// spectra of the two real signals that shared the transform
+__device__ __forceinline__ void mr_split(const float2 zk, const float2 zn, float2& X, float2& Y) {
+  X = float2{0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y)};
+  Y = float2{0.5f * (zk.y + zn.y), 0.5f * (zn.x - zk.x)};
+}
+
+template <int N>
+__global__ __launch_bounds__(64 * MrCfg<N>::WAVES) void mr_sums_kernel(MrArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int BUF = FftSize<N>::BUF, TW = FftSize<N>::TW, WV = MrCfg<N>::WAVES;
+  float2* const fbuf = (float2*)smem;
+  float2* const tw = fbuf + WV * BUF;
+  float* const wfull = (float*)(tw + TW);
+  float* const red = wfull + N;                      // [WV][3]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y, t = blockIdx.x * WV + wave;
+  fft_build_twiddles<N>(tw, tid, 64 * WV);
+  mr_window<N>(wfull, p.win, tid, 64 * WV);
+  __syncthreads();
+  float2* const buf = fbuf + wave * BUF;
+  mr_fill<N>(buf, wfull, p, b, t, lane);
+  fft_wave<N>(buf, tw, lane);
+  float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (t < p.F) {
+#pragma unroll
+    for (int r = 0; r < N / 128 + 1; ++r) {
+      const int k = lane + 64 * r;
+      if (k > N / 2) continue;
+      float2 X, Y;
+      mr_split(buf[fft_pad(k)], buf[fft_pad((N - k) & (N - 1))], X, Y);
+      const float xm = sqrtf(fmaxf(X.x * X.x + X.y * X.y, MR_EPS)), ym = sqrtf(fmaxf(Y.x * Y.x + Y.y * Y.y, MR_EPS));
+      const float d = ym - xm;
+      s1 += d * d;
+      s2 += ym * ym;
+      s3 += fabsf(logf(xm) - logf(ym));
+    }
+  }
+  s1 = svs_wave_sum(s1); s2 = svs_wave_sum(s2); s3 = svs_wave_sum(s3);
+  if (lane == 0) { red[wave * 3] = s1; red[wave * 3 + 1] = s2; red[wave * 3 + 2] = s3; }
+  __syncthreads();
+  if (tid < 3) {
+    float a = 0.f;
+    for (int w = 0; w < WV; ++w) a += red[w * 3 + tid];
+    p.partial[((long)b * gridDim.x + blockIdx.x) * 3 + tid] = a;
+  }
+}
+
+struct MrFinalArgs {
+  const float* partial[MR_NRES]; int nblk[MR_NRES]; double count[MR_NRES];
+  float grad_scale; float* loss; float* coef;        // coef: [MR_NRES][2]
+};
+__global__ __launch_bounds__(256) void mr_finalize_kernel(MrFinalArgs a) {
+  __shared__ double sh[MR_NRES][3][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int r = 0; r < MR_NRES; ++r) {
+    double s[3] = {0.0, 0.0, 0.0};
+    for (int i = tid; i < a.nblk[r]; i += 256)
+      for (int j = 0; j < 3; ++j) s[j] += (double)a.partial[r][(long)i * 3 + j];
+    for (int j = 0; j < 3; ++j) {
+      for (int o = 32; o > 0; o >>= 1) s[j] += __shfl_xor(s[j], o, 64);
+      if (lane == 0) sh[r][j][wave] = s[j];
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double total = 0.0;
+    for (int r = 0; r < MR_NRES; ++r) {
+      double s[3];
+      for (int j = 0; j < 3; ++j) s[j] = (sh[r][j][0] + sh[r][j][1]) + (sh[r][j][2] + sh[r][j][3]);
+      const double nd = sqrt(s[0]), ny = sqrt(s[1]);
+      total += (ny > 0.0 ? nd / ny : 0.0) + s[2] / a.count[r];
+      // d/d|X| of  ||Y|-|X||_F / ||Y||_F  is  -(|Y|-|X|) / (||Y|-|X||_F ||Y||_F);  of the mean log distance  sign / (count |X|)
+      a.coef[r * 2] = (nd > 0.0 && ny > 0.0) ? (float)((double)a.grad_scale / (MR_NRES * nd * ny)) : 0.f;
+      a.coef[r * 2 + 1] = (float)((double)a.grad_scale / (MR_NRES * a.count[r]));
+    }
+    a.loss[0] = (float)(total / MR_NRES);
+  }
+}
+
+template <int N>
+__global__ __launch_bounds__(64 * MrCfg<N>::WAVES) void mr_grad_kernel(MrArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int BUF = FftSize<N>::BUF, TW = FftSize<N>::TW, NR = N / 128 + 1, WV = MrCfg<N>::WAVES;
+  float2* const fbuf = (float2*)smem;
+  float2* const tw = fbuf + WV * BUF;
+  float* const wfull = (float*)(tw + TW);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y, ta = blockIdx.x * (2 * WV) + 2 * wave;
+  fft_build_twiddles<N>(tw, tid, 64 * WV);
+  mr_window<N>(wfull, p.win, tid, 64 * WV);
+  __syncthreads();
+  if (ta >= p.F) return;                             // (no barriers below: waves are independent)
+  float2* const buf = fbuf + wave * BUF;
+  const float csc = p.coef[0], clog = p.coef[1];
+  float2 H[2][NR];                                   // Hermitian-weighted dL/dX of frames ta, ta + 1
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    mr_fill<N>(buf, wfull, p, b, ta + h, lane);
+    fft_wave<N>(buf, tw, lane);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int k = lane + 64 * r;
+      float2 g = float2{0.f, 0.f};
+      if (k <= N / 2 && ta + h < p.F) {
+        float2 X, Y;
+        mr_split(buf[fft_pad(k)], buf[fft_pad((N - k) & (N - 1))], X, Y);
+        const float x2 = X.x * X.x + X.y * X.y;
+        if (x2 > MR_EPS) {                           // clamp(min=eps) passes no gradient below eps
+          const float xm = sqrtf(x2), ym = sqrtf(fmaxf(Y.x * Y.x + Y.y * Y.y, MR_EPS));
+          const float dl = logf(xm) - logf(ym);
+          const float gm = -csc * (ym - xm) + clog * (dl > 0.f ? 1.f : (dl < 0.f ? -1.f : 0.f)) / xm;   // dL/d|X|
+          const bool edge = (k == 0 || k == N / 2);
+          const float wgt = (edge ? 1.0f : 0.5f) * gm / xm;
+          g = float2{wgt * X.x, edge ? 0.f : wgt * X.y};
+        }
+      }
+      H[h][r] = g;
+    }
+  }
+  // conj(Z), Z = Ha + i Hb extended Hermitian; forward transform -> conj(ifft(Z)) = ga - i gb
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const int k = lane + 64 * r;
+    if (k > N / 2) continue;
+    const float2 a = H[0][r], c = H[1][r];
+    buf[fft_pad(k)] = float2{a.x - c.y, -(a.y + c.x)};
+    if (k > 0 && k < N / 2) buf[fft_pad(N - k)] = float2{a.x + c.y, -(c.x - a.y)};
+  }
+  fft_wave<N>(buf, tw, lane);
+  float* const fa = p.frames + ((long)b * p.F + ta) * N;
+#pragma unroll 4
+  for (int r = 0; r < N / 64; ++r) {
+    const int m = lane + 64 * r;
+    const float2 z = buf[fft_pad(m)];
+    const float w = wfull[m];
+    fa[m] = z.x * w;
+    if (ta + 1 < p.F) fa[N + m] = -z.y * w;
+  }
+}
+
+struct MrOlaArgs {
+  const float* frames[MR_NRES]; int n[MR_NRES], hop[MR_NRES], F[MR_NRES];
+  int B; long L; float* d_x;
+};
+// contributions of padded position q (= p + N/2) of one resolution to its sample: every frame t with hop t <= q < hop t + N
+__device__ __forceinline__ float mr_gather(const float* fr, int N, int hop, int F, long q) {
+  long t1 = q / hop;
+  if (t1 > F - 1) t1 = F - 1;
+  long t0 = q - (N - 1);
+  t0 = t0 <= 0 ? 0 : (t0 + hop - 1) / hop;
+  float s = 0.f;
+  for (long t = t0; t <= t1; ++t) s += fr[t * N + (q - t * hop)];
+  return s;
+}
+__global__ __launch_bounds__(256) void mr_ola_kernel(MrOlaArgs a) {
+  const long total = (long)a.B * a.L;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long b = i / a.L, nidx = i - b * a.L;
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < MR_NRES; ++r) {
+      const int N = a.n[r], half = N / 2;
+      const float* fr = a.frames[r] + b * (long)a.F[r] * N;
+      s += mr_gather(fr, N, a.hop[r], a.F[r], nidx + half);                                 // the sample itself
+      if (nidx >= 1 && nidx <= half) s += mr_gather(fr, N, a.hop[r], a.F[r], half - nidx);  // left mirror: p = -n
+      const long pr = 2 * (a.L - 1) - nidx;                                                  // right mirror: p = 2(L-1) - n
+      if (nidx <= a.L - 2 && pr < a.L + half) s += mr_gather(fr, N, a.hop[r], a.F[r], pr + half);
+    }
+    a.d_x[i] = s;
+  }
+}
+
+// ---- host side -----------------------------------------------------------------------------------
+template <int N> static size_t mr_lds_bytes() { return (size_t)MrCfg<N>::WAVES * FftSize<N>::BUF * 8 + FftSize<N>::TW * 8 + N * 4 + 8 * 3 * 4 + 64; }
+struct MrWs { float* partial[MR_NRES]; int nblk[MR_NRES]; float* frames[MR_NRES]; float* coef; size_t total; };
+static MrWs mr_layout(int B, long L, void* ws) {
+  MrWs w{};
+  char* base = (char*)ws;
+  size_t used = 0;
+  auto take = [&](size_t nfloats) { float* p = base ? (float*)(base + used) : nullptr; used += svs_align_up(nfloats * 4, 256); return p; };
+  w.coef = take(2 * MR_NRES);
+  for (int r = 0; r < MR_NRES; ++r) {
+    const int F = (int)(1 + L / MR_HOP[r]);
+    w.nblk[r] = B * ((F + mr_waves(MR_NFFT[r]) - 1) / mr_waves(MR_NFFT[r]));
+    w.partial[r] = take((size_t)w.nblk[r] * 3);
+    w.frames[r] = take((size_t)B * F * MR_NFFT[r]);
+  }
+  w.total = used;
+  return w;
+}
+extern "C" size_t svs_mrstft_workspace_bytes(int B, int64_t L) { return B > 0 && L > 0 ? mr_layout(B, L, nullptr).total : 0; }
+
+template <int N>
+static int mr_launch(bool grad, const MrArgs& a, int B, hipStream_t stream) {
+  const size_t lds = mr_lds_bytes<N>();
+  if (grad) {
+    SVS_HIP(hipFuncSetAttribute((const void*)mr_grad_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    constexpr int per = 2 * MrCfg<N>::WAVES;
+    hipLaunchKernelGGL(mr_grad_kernel<N>, dim3((unsigned)((a.F + per - 1) / per), (unsigned)B), dim3(64 * MrCfg<N>::WAVES), lds, stream, a);
+  } else {
+    SVS_HIP(hipFuncSetAttribute((const void*)mr_sums_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    constexpr int per = MrCfg<N>::WAVES;
+    hipLaunchKernelGGL(mr_sums_kernel<N>, dim3((unsigned)((a.F + per - 1) / per), (unsigned)B), dim3(64 * MrCfg<N>::WAVES), lds, stream, a);
+  }
+  SVS_CHECK_LAUNCH(grad ? "mr_grad" : "mr_sums");
+  return SVS_OK;
+}
+
+// loss[0] = MultiResolutionSTFTLoss(x, y); d_x (may be NULL) = grad_scale * d loss / d x.   x, y, d_x: (B, L) fp32.
+extern "C" int svs_mrstft_loss_fwd_bwd(const float* x, const float* y, int B, int64_t L, float grad_scale, float* loss, float* d_x,
+                                       void* ws, size_t ws_bytes, hipStream_t stream) {
+  SVS_REQUIRE(x && y && loss && B > 0 && L > 2048, "svs_mrstft_loss_fwd_bwd: bad arguments (need L > 2048 for reflect padding)");
+  const MrWs w = mr_layout(B, L, ws);
+  if (!ws || ws_bytes < w.total || !svs_aligned16(ws)) { svs_set_error("svs_mrstft_loss_fwd_bwd: workspace too small (%zu < %zu)", ws_bytes, w.total); return SVS_ERR_WORKSPACE; }
+  int rc;
+  MrArgs a[MR_NRES];
+  MrFinalArgs f{};
+  for (int r = 0; r < MR_NRES; ++r) {
+    a[r] = MrArgs{x, y, B, (long)L, MR_HOP[r], MR_WIN[r], (int)(1 + L / MR_HOP[r]), w.partial[r], w.coef + 2 * r, w.frames[r]};
+    rc = MR_NFFT[r] == 1024 ? mr_launch<1024>(false, a[r], B, stream) : MR_NFFT[r] == 2048 ? mr_launch<2048>(false, a[r], B, stream)
+                                                                                              : mr_launch<512>(false, a[r], B, stream);
+    if (rc) return rc;
+    f.partial[r] = w.partial[r]; f.nblk[r] = w.nblk[r];
+    f.count[r] = (double)B * a[r].F * (MR_NFFT[r] / 2 + 1);
+  }
+  f.grad_scale = grad_scale; f.loss = loss; f.coef = w.coef;
+  hipLaunchKernelGGL(mr_finalize_kernel, dim3(1), dim3(256), 0, stream, f);
+  SVS_CHECK_LAUNCH("mr_finalize");
+  if (!d_x) return SVS_OK;
+  MrOlaArgs o{};
+  for (int r = 0; r < MR_NRES; ++r) {
+    rc = MR_NFFT[r] == 1024 ? mr_launch<1024>(true, a[r], B, stream) : MR_NFFT[r] == 2048 ? mr_launch<2048>(true, a[r], B, stream)
+                                                                                             : mr_launch<512>(true, a[r], B, stream);
+    if (rc) return rc;
+    o.frames[r] = w.frames[r]; o.n[r] = MR_NFFT[r]; o.hop[r] = MR_HOP[r]; o.F[r] = a[r].F;
+  }
+  o.B = B; o.L = L; o.d_x = d_x;
+  long g = ((long)B * L + 255) / 256;
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(mr_ola_kernel, dim3((unsigned)g), dim3(256), 0, stream, o);
+  SVS_CHECK_LAUNCH("mr_ola");
+  return SVS_OK;
+}

@@ -734,13 +734,62 @@ extern "C" int svs_unet_train_fwd_loss(const float* params, float* bn_buffers, i
   return svs_l1_mask_loss_fwd_bwd(m, mix, voc, g.P[0], loss_scale, t.d_logit, loss, t.bnws, t.bnws_bytes, stream);
 }
 
+// The reference's full objective (train.py:274-296): alpha_L1 * (L1 vocal + L1 accompaniment) + alpha_MR * MR-STFT(
+// specific_istft(mask * mix, mix_phase), specific_istft(voc, voc_phase)).  Forward + both losses + d(total)/d(logit); the
+// backward follows with svs_unet_train_bwd_part (part 4 = the whole pass, or the split forms).  Needs H = n_fft / 2 = 512.
+//   losses[0] = L1 part (unscaled), losses[1] = MR part (unscaled); total = alpha_l1 * losses[0] + alpha_mr * losses[1]
+//   mr_ws: svs_unet_train_mr_workspace_bytes(B, W, hop) bytes (waveforms, their gradient, the loss's frame buffers)
+struct MrTrainWs { float* wav_pred; float* wav_tgt; float* d_wav; void* mr; size_t mr_bytes; size_t total; };
+static MrTrainWs mr_train_layout(int B, int W, int hop, void* ws) {
+  MrTrainWs m{};
+  Arena a{(char*)ws, 0};
+  const size_t L = (size_t)hop * (W - 1);
+  m.wav_pred = a.take((size_t)B * L);
+  m.wav_tgt = a.take((size_t)B * L);
+  m.d_wav = a.take((size_t)B * L);
+  m.mr_bytes = svs_mrstft_workspace_bytes(B, (int64_t)L);
+  m.mr = a.take(m.mr_bytes / sizeof(float) + 64);
+  m.total = a.used;
+  return m;
+}
+extern "C" size_t svs_unet_train_mr_workspace_bytes(int B, int W, int hop) {
+  if (B <= 0 || W < 2 || hop <= 0) return 0;
+  return mr_train_layout(B, W, hop, nullptr).total;
+}
+extern "C" int svs_unet_train_fwd_loss_mr(const float* params, float* bn_buffers, int64_t* num_batches_tracked, const float* mix,
+                                          const float* voc, const float* mix_phase, const float* voc_phase, const float* drop,
+                                          int B, int H, int W, int hop, float alpha_l1, float alpha_mr, float* mask, float* losses,
+                                          void* ws, size_t ws_bytes, void* mr_ws, size_t mr_ws_bytes, hipStream_t stream) {
+  Geo g; TrainWs t;
+  int rc = make_geo(B, H, W, g);
+  if (rc) return rc;
+  SVS_REQUIRE(params && mix && voc && mix_phase && voc_phase && losses && svs_aligned16(params) && svs_aligned16(mix),
+              "svs_unet_train_fwd_loss_mr: bad pointers");
+  SVS_REQUIRE(H == 512 && W >= 2 && hop >= 512 && hop <= 1024, "svs_unet_train_fwd_loss_mr: needs H = 512 (n_fft 1024) and 512 <= hop <= 1024");
+  if ((rc = check_train_ws("svs_unet_train_fwd_loss_mr", g, ws, ws_bytes, t))) return rc;
+  const MrTrainWs m = mr_train_layout(B, W, hop, mr_ws);
+  if (!mr_ws || mr_ws_bytes < m.total || !svs_aligned16(mr_ws)) { svs_set_error("svs_unet_train_fwd_loss_mr: MR workspace too small (%zu < %zu)", mr_ws_bytes, m.total); return SVS_ERR_WORKSPACE; }
+  float* mk = mask ? mask : t.mask;
+  if ((rc = train_forward_impl(view_params(params), bn_buffers, num_batches_tracked, mix, drop, g, t, mk, stream))) return rc;
+  // d_logit = alpha_l1 * d(L1)/d(logit)                                                   (train.py:281-283,296)
+  if ((rc = svs_l1_mask_loss_fwd_bwd(mk, mix, voc, g.P[0], alpha_l1, t.d_logit, losses, t.bnws, t.bnws_bytes, stream))) return rc;
+  // waveforms: predicted magnitude (mask * mix, fused into the inverse's load) with the MIXTURE phase, target with its own
+  const int64_t cs = (int64_t)H * W;
+  const long L = (long)hop * (W - 1);
+  if ((rc = svs_istft_tiles(mix, cs, W, H, 1, mk, 0, mix_phase, 3, B, 2 * H, hop, W, m.wav_pred, nullptr, stream))) return rc;   // train.py:288
+  if ((rc = svs_istft_tiles(voc, cs, W, H, 1, nullptr, 0, voc_phase, 3, B, 2 * H, hop, W, m.wav_tgt, nullptr, stream))) return rc; // train.py:291
+  if ((rc = svs_mrstft_loss_fwd_bwd(m.wav_pred, m.wav_tgt, B, L, alpha_mr, losses + 1, m.d_wav, m.mr, m.mr_bytes, stream))) return rc;  // train.py:293
+  // d_logit += d(alpha_mr * MR)/d(wav) through the inverse STFT and |S| = mask * mix
+  return svs_istft_bwd_mask(m.d_wav, mix_phase, mix, mk, t.d_logit, 1.0f, B, 2 * H, hop, W, stream);
+}
+
 extern "C" int svs_unet_train_bwd_part(const float* params, float* grads, const float* mix, const float* drop, int B, int H, int W,
                                        int part, void* ws, size_t ws_bytes, hipStream_t stream) {
   Geo g; TrainWs t;
   int rc = make_geo(B, H, W, g);
   if (rc) return rc;
-  SVS_REQUIRE(params && grads && mix && part >= 0 && part <= 3, "svs_unet_train_bwd_part: bad arguments");
+  SVS_REQUIRE(params && grads && mix && part >= 0 && part <= 4, "svs_unet_train_bwd_part: bad arguments");
   if ((rc = check_train_ws("svs_unet_train_bwd_part", g, ws, ws_bytes, t))) return rc;
-  static const int bits[4] = {1, 2 | 4, 2, 4};     // decoder | whole encoder | conv6 block | conv5..conv1 blocks
+  static const int bits[5] = {1, 2 | 4, 2, 4, 7};  // decoder | whole encoder | conv6 block | conv5..conv1 blocks | everything
   return train_backward_impl(view_params(params), grads, mix, drop, g, t, stream, bits[part]);
 }

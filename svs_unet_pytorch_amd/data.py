@@ -67,15 +67,58 @@ def istft(mag: torch.Tensor, phase: torch.Tensor, n_fft: int = WINDOW_SIZE, hop:
 
 
 def specific_istft(magnitude: torch.Tensor, phase: torch.Tensor, n_fft: int = WINDOW_SIZE, hop: int = HOP_SIZE):
-    """train.py:33-60: (B,1,512,T) magnitude and angle (DC row dropped) -> (B,1,hop*(T-1)) waveforms."""
+    """train.py:33-60: (B,1,512,T) magnitude and angle (DC row dropped) -> (B,1,hop*(T-1)) waveforms, ONE launch for the
+    whole batch (the DC row that train.py:41-42 pads back is the absent first row of the tile layout)."""
     B, _, F_, T = magnitude.shape
-    out = torch.empty((B, 1, hop * (T - 1)), dtype=torch.float32, device=magnitude.device)
-    zero = torch.zeros((1, T), dtype=torch.float32, device=magnitude.device)
-    for b in range(B):
-        m = torch.cat([zero, magnitude[b, 0].float()], dim=0)          # train.py:41-42
-        a = torch.cat([zero, phase[b, 0].float()], dim=0)
-        out[b, 0] = istft(m, a, n_fft, hop)
+    m = magnitude.contiguous().float()
+    a = phase.contiguous().float()
+    out = torch.empty((B, 1, hop * (T - 1)), dtype=torch.float32, device=m.device)
+    _lib.check(_lib.lib().svs_istft_tiles(m.data_ptr(), F_ * T, T, F_, 1, None, 0, a.data_ptr(), 3, B, n_fft, hop, T, out.data_ptr(), None,
+                                          _lib.stream_ptr()), "svs_istft_tiles")
     return out
+
+
+def stft_to_tiles(y: torch.Tensor, n_fft: int = WINDOW_SIZE, hop: int = HOP_SIZE, seg: int = 128):
+    """float32 (channels, n) on the GPU -> (tiles (channels, n_tiles, 1, n_fft/2, seg) magnitude with the DC row dropped and the
+    last tile zero-padded (inference.py:68,84-92), frame-major unit phasors (channels, T, n_fft/2+1) complex64, the maximum
+    magnitude per channel (channels,) incl. the DC row (data.py:84), T).  One launch; nothing is repacked afterwards."""
+    L = _lib.lib()
+    y = y.contiguous().float()
+    C, n = y.shape
+    T = int(L.svs_stft_frames(n, hop))
+    n_tiles = T // seg + (1 if T % seg else 0)                      # the empty last segment is skipped (inference.py:88)
+    rows = n_fft // 2
+    tiles = torch.empty((C, n_tiles, 1, rows, seg), dtype=torch.float32, device=y.device)
+    phase = torch.empty((C, T, rows + 1, 2), dtype=torch.float32, device=y.device)
+    groups = int(L.svs_stft_groups(n_tiles * seg))
+    part = torch.empty((C, groups), dtype=torch.float32, device=y.device)
+    _lib.check(L.svs_stft_tiles(y.data_ptr(), n, C, n_fft, hop, tiles.data_ptr(), n_tiles * rows * seg, seg, rows, 1, n_tiles * seg,
+                                phase.data_ptr(), 1, part.data_ptr(), _lib.stream_ptr()), "svs_stft_tiles")
+    peak = torch.empty(C, dtype=torch.float32, device=y.device)
+    for c in range(C):
+        _lib.check(L.svs_max(part[c].data_ptr(), groups, peak[c:].data_ptr(), _lib.stream_ptr()), "svs_max")
+    return tiles, torch.view_as_complex(phase), peak, T
+
+
+def istft_from_tiles(tiles: torch.Tensor, mask, phase_fm: torch.Tensor, frames: int, invert: bool = False,
+                     n_fft: int = WINDOW_SIZE, hop: int = HOP_SIZE, peak: float | None = None):
+    """(channels, n_tiles, 1, 512, seg) magnitude tiles [times mask or 1 - mask, fused: inference.py:100-107] and frame-major
+    phasors (channels, T, 513) -> (channels, hop*(T-1)) samples, optionally peak-normalised per channel (data.py:162-164)."""
+    L = _lib.lib()
+    C, n_tiles, _, rows, seg = tiles.shape
+    ph = torch.view_as_real(phase_fm.contiguous()).contiguous()
+    y = torch.empty((C, hop * (frames - 1)), dtype=torch.float32, device=tiles.device)
+    groups = int(L.svs_istft_groups(hop, frames))
+    part = torch.empty((C, groups), dtype=torch.float32, device=tiles.device) if peak is not None else None
+    _lib.check(L.svs_istft_tiles(tiles.data_ptr(), n_tiles * rows * seg, seg, rows, 1, None if mask is None else mask.data_ptr(),
+                                 1 if invert else 0, ph.data_ptr(), 1, C, n_fft, hop, frames, y.data_ptr(),
+                                 None if part is None else part.data_ptr(), _lib.stream_ptr()), "svs_istft_tiles")
+    if peak is not None:
+        pk = torch.empty(C, dtype=torch.float32, device=tiles.device)
+        for c in range(C):
+            _lib.check(L.svs_max(part[c].data_ptr(), groups, pk[c:].data_ptr(), _lib.stream_ptr()), "svs_max")
+            _lib.check(L.svs_scale_by_inv(y[c].data_ptr(), y.shape[1], pk[c:].data_ptr(), float(peak), _lib.stream_ptr()), "svs_scale_by_inv")
+    return y
 
 
 # ------------------------------------------------------------------------------------------------

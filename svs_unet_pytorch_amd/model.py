@@ -48,6 +48,7 @@ def _on_model_device(fn):
 ENC_CHANNELS = (1, 16, 32, 64, 128, 256, 512)                                   # model.py:47-76
 DEC_IO = ((512, 256), (512, 128), (256, 64), (128, 32), (64, 16), (32, 1))      # model.py:79-109
 ALPHA_L1 = 166.66                                                                # train.py:24
+ALPHA_MR = 0.66                                                                  # train.py:25
 
 
 class WeightedL1Loss(nn.Module):
@@ -210,6 +211,7 @@ class UNet(nn.Module):
         self.dropout_seed = 4242
         self._xstream = None            # stream the overlapped gradient exchange is issued from
         self.dropout_step = 0
+        self.last_mr_loss = None        # MR-STFT part of the last training objective (device scalar) or None
         self.rank = 0
         self._flatten()
 
@@ -416,11 +418,46 @@ class UNet(nn.Module):
             return _TrainForward.apply(self._anchor, mix, self)
         return self._train_forward(mix)
 
+    def _mr_workspace(self, B, W, hop):
+        key = ("mr", B, W, hop)
+        ws = self._ws.get(key)
+        if ws is None:
+            ws = torch.empty(int(lib().svs_unet_train_mr_workspace_bytes(B, W, hop)), dtype=torch.uint8, device=self._flat.device)
+            self._ws[key] = ws
+        return ws
+
+    def _fwd_losses(self, mix, voc, loss_scale, mix_phase, voc_phase, alpha_mr, ws):
+        """Forward + loss(es) + d(objective)/d(logit) left in the workspace.  Returns the L1 part as a device scalar; with
+        phases and alpha_mr != 0 the multi-resolution STFT term of train.py:287-296 is part of the objective and its value
+        is kept in `self.last_mr_loss`."""
+        B, _, H, W = mix.shape
+        L = lib()
+        if mix_phase is None or not alpha_mr:
+            self.last_mr_loss = None
+            loss = torch.empty(1, dtype=torch.float32, device=mix.device)
+            check(L.svs_unet_train_fwd_loss(ptr(self._flat), ptr(self._bn_flat), ptr(self._nbt_flat), ptr(mix), ptr(voc), ptr(self._drop),
+                                            B, H, W, float(loss_scale), None, ptr(loss), ptr(ws), ws.numel(), _lib.stream_ptr()),
+                  "svs_unet_train_fwd_loss")
+            return loss[0]
+        from .config import HOP_SIZE
+        mix_phase, voc_phase = self._check_input(mix_phase), self._check_input(voc_phase)
+        if mix_phase.shape != mix.shape or voc_phase.shape != mix.shape:
+            raise ValueError("phase tensors must have the shape of the magnitude tiles")
+        mr_ws = self._mr_workspace(B, W, HOP_SIZE)
+        losses = torch.empty(2, dtype=torch.float32, device=mix.device)
+        check(L.svs_unet_train_fwd_loss_mr(ptr(self._flat), ptr(self._bn_flat), ptr(self._nbt_flat), ptr(mix), ptr(voc), ptr(mix_phase),
+                                           ptr(voc_phase), ptr(self._drop), B, H, W, HOP_SIZE, float(loss_scale), float(alpha_mr), None,
+                                           ptr(losses), ptr(ws), ws.numel(), ptr(mr_ws), mr_ws.numel(), _lib.stream_ptr()),
+              "svs_unet_train_fwd_loss_mr")
+        self.last_mr_loss = losses[1]
+        return losses[0]
+
     @_on_model_device
-    def fwd_bwd(self, mix, voc, loss_scale=1.0):
-        """Fused training forward + L1 loss (train.py:274-283) + backward in one library call.
-        Gradients of `loss_scale * loss` land in the flat gradient buffer; returns the unscaled loss
-        as a device scalar (no host sync)."""
+    def fwd_bwd(self, mix, voc, loss_scale=1.0, mix_phase=None, voc_phase=None, alpha_mr=0.0):
+        """Fused training forward + loss + backward.  Objective: loss_scale * L1 terms (train.py:274-283) [+ alpha_mr *
+        MR-STFT of the re-synthesised waveforms (train.py:287-296) when the phase tiles are given].  Gradients land in the
+        flat gradient buffer; returns the unscaled L1 part as a device scalar (no host sync); the MR part, when
+        computed, is `self.last_mr_loss`."""
         mix, voc = self._check_input(mix), self._check_input(voc)
         B, _, H, W = mix.shape
         ws = self._workspace("train", B, H, W)
@@ -428,17 +465,24 @@ class UNet(nn.Module):
         self._generation += 1
         self._param_epoch += 1
         target, tmp = self._grad_target()
-        loss = torch.empty(1, dtype=torch.float32, device=mix.device)
-        check(lib().svs_unet_train_fwd_bwd(ptr(self._flat), ptr(target), ptr(self._bn_flat), ptr(self._nbt_flat), ptr(mix),
-                                           ptr(voc), ptr(self._drop), B, H, W, float(loss_scale), None, ptr(loss), ptr(ws),
-                                           ws.numel(), _lib.stream_ptr()), "svs_unet_train_fwd_bwd")
+        if mix_phase is None or not alpha_mr:
+            self.last_mr_loss = None
+            loss = torch.empty(1, dtype=torch.float32, device=mix.device)
+            check(lib().svs_unet_train_fwd_bwd(ptr(self._flat), ptr(target), ptr(self._bn_flat), ptr(self._nbt_flat), ptr(mix),
+                                               ptr(voc), ptr(self._drop), B, H, W, float(loss_scale), None, ptr(loss), ptr(ws),
+                                               ws.numel(), _lib.stream_ptr()), "svs_unet_train_fwd_bwd")
+            loss = loss[0]
+        else:
+            loss = self._fwd_losses(mix, voc, loss_scale, mix_phase, voc_phase, alpha_mr, ws)
+            check(lib().svs_unet_train_bwd_part(ptr(self._flat), ptr(target), ptr(mix), ptr(self._drop), B, H, W, 4, ptr(ws),
+                                                ws.numel(), _lib.stream_ptr()), "svs_unet_train_bwd_part")
         if tmp is not None:
             self._gflat.add_(tmp)
         self._grads_clean = False
-        return loss[0]
+        return loss
 
     @_on_model_device
-    def fwd_bwd_overlapped(self, mix, voc, loss_scale, grad_sync):
+    def fwd_bwd_overlapped(self, mix, voc, loss_scale, grad_sync, mix_phase=None, voc_phase=None, alpha_mr=0.0):
         """Same result as fwd_bwd, as four library calls so that the gradient exchange overlaps the backward:
         forward + loss; backward of the decoder half (its gradients occupy the tail of the flat buffer) followed
         at once by an asynchronous all-reduce of that tail; the conv6 block and its all-reduce; conv5..conv1 and theirs.
@@ -451,11 +495,8 @@ class UNet(nn.Module):
         self._param_epoch += 1
         self._attach_grads()
         assert self._grads_clean, "overlapped exchange needs zero_grad() first (it overwrites the flat gradient buffer)"
-        loss = torch.empty(1, dtype=torch.float32, device=mix.device)
         L = lib()
-        check(L.svs_unet_train_fwd_loss(ptr(self._flat), ptr(self._bn_flat), ptr(self._nbt_flat), ptr(mix), ptr(voc), ptr(self._drop),
-                                        B, H, W, float(loss_scale), None, ptr(loss), ptr(ws), ws.numel(), _lib.stream_ptr()),
-              "svs_unet_train_fwd_loss")
+        loss = self._fwd_losses(mix, voc, loss_scale, mix_phase, voc_phase, alpha_mr, ws)
         split = int(L.svs_unet_param_offset(24))           # first decoder tensor (deconv1.weight)
         c6 = int(L.svs_unet_param_offset(20))              # conv6.weight: the conv6 block is 13 of the encoder's 17.5 MB
         handles = []
@@ -474,20 +515,20 @@ class UNet(nn.Module):
             with torch.cuda.stream(xs):
                 handles.append(grad_sync.reduce_async(sl))
         self._grads_clean = False
-        return loss[0], handles
+        return loss, handles
 
-    def train_step(self, mix, voc, loss_scale=1.0, grad_sync=None):
+    def train_step(self, mix, voc, loss_scale=1.0, grad_sync=None, mix_phase=None, voc_phase=None, alpha_mr=0.0):
         """zero_grad + fwd_bwd + (optional gradient all-reduce) + Adam: the whole of train.py:271-300
         (L1 terms).  `grad_sync` is the data-parallel hook (parallel.GradAllReduce): with `reduce_async` the
         exchange of the decoder half overlaps the encoder half's backward, otherwise `grad_sync(flat_grad)`
         runs after the backward."""
         self.optim.zero_grad()
         if grad_sync is not None and getattr(grad_sync, "overlap", False):
-            loss, handles = self.fwd_bwd_overlapped(mix, voc, loss_scale, grad_sync)
+            loss, handles = self.fwd_bwd_overlapped(mix, voc, loss_scale, grad_sync, mix_phase, voc_phase, alpha_mr)
             for h in handles:
                 h.wait()
         else:
-            loss = self.fwd_bwd(mix, voc, loss_scale)
+            loss = self.fwd_bwd(mix, voc, loss_scale, mix_phase, voc_phase, alpha_mr)
             if grad_sync is not None:
                 grad_sync(self._gflat)
         self.optim.step()

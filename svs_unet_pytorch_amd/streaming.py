@@ -1,6 +1,6 @@
 """End-to-end on-GPU separation of a waveform: STFT -> normalise -> 128-frame tiles -> U-Net mask -> masked
 magnitude x mixture phase -> inverse STFT -> peak-normalise, with every intermediate resident in HBM
-(BASELINE.json configs[4], in fp32; the bf16 MFMA variant is not built yet).
+(BASELINE.json configs[4]).
 
 This is the composition of the reference's three CLI stages without the .npy round trips:
   data.py to_spec   (data.py:78-109)     svs_stft_fwd + svs_absmax + svs_scale_by_inv
@@ -15,7 +15,7 @@ import torch
 
 from . import _lib
 from .config import HOP_SIZE, INPUT_LEN, WINDOW_SIZE
-from .data import istft, stft_magphase
+from .data import istft_from_tiles, stft_to_tiles
 
 
 @torch.no_grad()
@@ -46,15 +46,25 @@ def separate_spectrogram_device(model, mag: torch.Tensor, seg_len: int = INPUT_L
 
 @torch.no_grad()
 def separate_waveform(model, y: torch.Tensor, vocal_solo: bool = True, n_fft: int = WINDOW_SIZE, hop: int = HOP_SIZE,
-                      peak: float | None = 0.9):
-    """float32 samples (n,) or (channels, n) on the GPU -> separated samples (hop*(T-1),) or (channels, hop*(T-1))."""
-    if y.dim() == 2:
-        return torch.stack([separate_waveform(model, y[c], vocal_solo, n_fft, hop, peak) for c in range(y.shape[0])])
-    mag, phase = stft_magphase(y, n_fft, hop)
+                      peak: float | None = 0.9, max_batch: int = 256):
+    """float32 samples (n,) or (channels, n) on the GPU -> separated samples (hop*(T-1),) or (channels, hop*(T-1)).
+    All channels go through ONE forward transform (which writes network tiles and frame-major phasors directly), one
+    batched network forward per `max_batch` tiles and ONE inverse transform (which applies the mask on load and
+    overlap-adds in LDS); the only other passes are the two per-channel normalisations."""
+    squeeze = y.dim() == 1
+    if squeeze:
+        y = y[None]
+    tiles, phase, norm, T = stft_to_tiles(y, n_fft, hop, INPUT_LEN)
     L = _lib.lib()
-    ws = torch.empty(4096, dtype=torch.uint8, device=y.device)
-    norm = torch.empty(1, dtype=torch.float32, device=y.device)
-    _lib.check(L.svs_absmax(mag.data_ptr(), mag.numel(), norm.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr()), "svs_absmax")
-    _lib.check(L.svs_scale_by_inv(mag.data_ptr(), mag.numel(), norm.data_ptr(), 1.0, _lib.stream_ptr()), "svs_scale_by_inv")
-    pred = separate_spectrogram_device(model, mag, INPUT_LEN, vocal_solo)
-    return istft(pred, phase, n_fft, hop, peak=peak)
+    C, n_tiles = tiles.shape[:2]
+    for c in range(C):                                           # divide by the channel's maximum magnitude (data.py:84-85,105)
+        _lib.check(L.svs_scale_by_inv(tiles[c].data_ptr(), tiles[c].numel(), norm[c:].data_ptr(), 1.0, _lib.stream_ptr()), "svs_scale_by_inv")
+    flat = tiles.view(C * n_tiles, 1, tiles.shape[3], tiles.shape[4])
+    mask = torch.empty_like(flat)
+    was_training = model.training
+    model.eval()
+    for s in range(0, flat.shape[0], max_batch):
+        mask[s:s + max_batch] = model(flat[s:s + max_batch])
+    model.train(was_training)
+    out = istft_from_tiles(tiles, mask, phase, T, invert=not vocal_solo, n_fft=n_fft, hop=hop, peak=peak)
+    return out[0] if squeeze else out

@@ -143,3 +143,51 @@ def test_resident_training_set(tmp_path, report):
         seen += m.shape[0]
     assert seen == 12 and res.num_batches(5) == 3
 
+
+
+def test_resident_set_matches_reference_dataset_items(tmp_path, golden, report):
+    """The HBM-resident training set against the reference's OWN SpectrogramDataset (tests/golden/dataset_items.npz,
+    captured by running /root/reference/train.py as a script): magnitudes bit for bit (sha256), angles (np.angle done on
+    the device with atan2f) to 1e-6 rad, with the start drawn exactly as train.py:121 draws it."""
+    import hashlib
+    import random
+    g = golden("dataset_items.npz")
+    lengths = [int(t) for t in g["lengths"]]
+    root = tmp_path / "spec"
+    os.makedirs(root / "mixture"), os.makedirs(root / "vocal")
+    songs = {}
+    for n, T in enumerate(lengths):
+        mix, voc, pm, pv = synth.song(n, T)
+        songs[n] = (mix, voc, pm, pv)
+        base = f"{n:04d}_len{T}"
+        np.save(root / "mixture" / f"{base}_spec.npy", mix), np.save(root / "vocal" / f"{base}_spec.npy", voc)
+        np.save(root / "mixture" / f"{base}_phase.npy", pm), np.save(root / "vocal" / f"{base}_phase.npy", pv)
+    ds = svs_train.SpectrogramDataset(str(root))
+    assert len(ds) == int(g["len"])
+    res = svs_train.ResidentSpectrograms(ds, torch.device("cuda"))
+    assert res.has_phase
+    sha = lambda a: np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8)
+    worst = 0.0
+    for seed in g["seeds"]:
+        items = [0, 1, 2, 3, 5, 6]
+        starts = []
+        for idx in items:                                  # the reference seeds per item in the generator; one draw per item
+            random.seed(int(seed) * 1000 + idx)
+            s_, st_ = res.draw([idx], rng=random)
+            assert s_ == [idx % len(lengths)]
+            starts.append(st_[0])
+            assert st_[0] == int(g[f"s{int(seed)}.i{idx}.start"])
+        mix, voc, mph, vph = res.crop([i % len(lengths) for i in items], starts, with_phase=True)
+        for b, idx in enumerate(items):
+            p = f"s{int(seed)}.i{idx}."
+            assert np.array_equal(sha(mix[b].cpu().numpy()), g[p + "mix_sha"]), p
+            assert np.array_equal(sha(voc[b].cpu().numpy()), g[p + "voc_sha"]), p
+            n = idx % len(lengths)
+            for got, z, key in ((mph[b], songs[n][2], "mix_phase_sha"), (vph[b], songs[n][3], "voc_phase_sha")):
+                want = to.crop_phase(z, starts[b])
+                assert np.array_equal(sha(want), g[p + key])           # the oracle IS the reference here (bit-exact)
+                d = np.abs(got.cpu().numpy() - want)
+                d = np.minimum(d, 2 * np.pi - d)                        # +pi and -pi are the same angle
+                worst = max(worst, float(d.max()))
+    assert report("resident phase tiles vs reference SpectrogramDataset (rad)", worst, 1e-6)
+    report("resident magnitude tiles vs reference SpectrogramDataset (sha256)", 0.0, 0.0)

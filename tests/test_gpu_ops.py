@@ -608,3 +608,90 @@ def test_specific_istft_golden(golden, report):
     assert got.shape == want.shape == (2, 1, 97536)
     e = np.abs(got - want)[..., 1024:-1024].max() / np.abs(want).max()
     assert report("specific_istft vs reference function (interior)", e, 2e-5)
+
+
+# ------------------------------------------------------------------------------------------------
+# batched / tiled signal kernels (csrc/stft.hip, csrc/mrstft.hip)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [200000, 98304 + 5, 768 * 130])      # T = 261 (3 tiles, ragged), 129 (2 tiles, 127 pad), 131
+def test_stft_tiles_istft_tiles(n, report):
+    """Forward transform straight into network tiles (DC row dropped, last tile zero-padded) with frame-major phasors, and
+    the fused inverse (mask applied on load, overlap-add in LDS, per-channel peak), two channels in one launch, against the
+    numpy oracle of data.py:78-109,151-166 / inference.py:65-127."""
+    from svs_unet_pytorch_amd.data import istft_from_tiles, stft_to_tiles
+    y_np = np.stack([synth.audio(n, 0), synth.audio(n, 1) * 0.5])
+    tiles, phase, peak, T = stft_to_tiles(torch.from_numpy(y_np).to(DEV))
+    assert T == 1 + n // 768
+    n_tiles = T // 128 + (1 if T % 128 else 0)
+    assert tiles.shape == (2, n_tiles, 1, 512, 128) and phase.shape == (2, T, 513)
+    mask = torch.from_numpy(synth.uniform(9, tiles.numel()).reshape(tiles.shape)).to(DEV)
+    got_plain = istft_from_tiles(tiles, None, phase, T).cpu().numpy()
+    got_masked = istft_from_tiles(tiles, mask, phase, T, invert=True, peak=0.9).cpu().numpy()
+    tiles_h, phase_h, mask_h = tiles.cpu().numpy(), phase.cpu().numpy(), mask.cpu().numpy()
+    for c in range(2):
+        d = so.stft(y_np[c])
+        mag_o, ph_o = so.magphase(d)
+        scale = mag_o.max()
+        assert report(f"stft_tiles n={n} ch{c} peak", abs(peak[c].item() - scale) / scale, 2e-6)
+        full = tiles_h[c, :, 0].transpose(1, 0, 2).reshape(512, n_tiles * 128)
+        assert report(f"stft_tiles n={n} ch{c} magnitude", np.abs(full[:, :T] - mag_o[1:]).max() / scale, 2e-6)
+        assert np.all(full[:, T:] == 0)                                         # tile padding (inference.py:90-92)
+        big = mag_o.T > 1e-3 * scale
+        assert report(f"stft_tiles n={n} ch{c} phasors", np.abs(phase_h[c] - ph_o.T)[big].max(), 2e-4)
+        # inverse: DC bin absent (inference.py:123 puts a ZERO row back), mixture phase
+        spec = np.concatenate([np.zeros((1, T), np.float32), full[:, :T]], axis=0) * ph_o
+        want = so.istft(spec)
+        e = np.abs(got_plain[c] - want)[1024:-1024].max() / np.abs(want).max()
+        assert report(f"istft_tiles n={n} ch{c} (interior)", e, 2e-5)
+        mfull = 1.0 - mask_h[c, :, 0].transpose(1, 0, 2).reshape(512, n_tiles * 128)[:, :T]
+        spec_m = np.concatenate([np.zeros((1, T), np.float32), full[:, :T] * mfull], axis=0) * ph_o
+        want_m = so.istft(spec_m)
+        e = np.abs(got_masked[c] / 0.9 * np.abs(want_m).max() - want_m)[1024:-1024].max() / np.abs(want_m).max()
+        assert report(f"istft_tiles n={n} ch{c} masked + peak-normalised (interior)", e, 5e-5)
+        assert report(f"istft_tiles n={n} ch{c} peak 0.9", abs(np.abs(got_masked[c]).max() - 0.9), 1e-5)
+
+
+def test_istft_bwd_mask(golden, report):
+    """Transpose of specific_istft fused with |S| = mask * mix: against the gradient that autograd gave on the reference's
+    own specific_istft (tests/golden/specific_istft.npz) and the oracle's adjoint."""
+    g = golden("specific_istft.npz")
+    B, T = 2, 128
+    ang = (synth.uniform(4, B * 512 * T) * 2 * np.pi - np.pi).astype(np.float32).reshape(B, 1, 512, T)
+    wgt = (synth.uniform(8, B * 97536).reshape(B, 1, 97536).astype(np.float64) - 0.5)
+    mix = synth.uniform(10, B * 512 * T).reshape(B, 1, 512, T)
+    mask = synth.uniform(11, B * 512 * T).reshape(B, 1, 512, T) * 0.8 + 0.1
+    d0 = synth.uniform(12, B * 512 * T).reshape(B, 1, 512, T) - 0.5
+    d_logit = torch.from_numpy(d0.copy()).to(DEV)
+    dw = torch.from_numpy(wgt.astype(np.float32)).to(DEV)
+    _lib.check(L().svs_istft_bwd_mask(dw.data_ptr(), torch.from_numpy(ang).to(DEV).data_ptr(), torch.from_numpy(mix).to(DEV).data_ptr(),
+                                      torch.from_numpy(mask).to(DEV).data_ptr(), d_logit.data_ptr(), 0.37, B, 1024, 768, T, S()))
+    dmag = so.specific_istft_adjoint(wgt, ang)                                   # pinned against the reference in the CPU suite
+    want = d0 + 0.37 * dmag * mix * mask * (1 - mask)
+    scale = np.abs(0.37 * dmag * mix * mask * (1 - mask)).max()
+    assert report("istft_bwd_mask vs oracle adjoint", np.abs(d_logit.cpu().numpy() - want).max() / scale, 2e-5)
+    # and directly against the reference's autograd numbers: rows 0..3 of tile 0
+    got_dmag = (d_logit.cpu().numpy() - d0)[0, 0, :4] / (0.37 * mix * mask * (1 - mask))[0, 0, :4]
+    assert report("istft_bwd_mask vs reference autograd (rows 0-3)", np.abs(got_dmag - g["dmag_tile0_rows"]).max() / np.abs(g["dmag_tile0_rows"]).max(), 2e-4)
+
+
+@pytest.mark.parametrize("B,L_", [(2, 97536), (3, 20000)])
+def test_mrstft_loss_and_gradient(B, L_, report):
+    """Multi-resolution STFT loss (train.py:26,293) value and gradient against the torch restatement of its published
+    definition (oracle/mrstft_oracle.py, float64 + autograd).  auraloss itself: parity unpinned."""
+    from oracle import mrstft_oracle as mo
+    x = (synth.uniform(20, B * L_).reshape(B, L_) - 0.5) * 0.4
+    y = x * 0.7 + (synth.uniform(21, B * L_).reshape(B, L_) - 0.5) * 0.2
+    want_loss, want_grad = mo.mrstft_loss_and_grad(torch.from_numpy(x).double(), torch.from_numpy(y).double())
+    xd, yd = torch.from_numpy(x).to(DEV), torch.from_numpy(y).to(DEV)
+    ws = ws_tensor(L().svs_mrstft_workspace_bytes(B, L_))
+    loss = torch.zeros(1, device=DEV)
+    dx = torch.empty_like(xd)
+    _lib.check(L().svs_mrstft_loss_fwd_bwd(xd.data_ptr(), yd.data_ptr(), B, L_, 2.5, loss.data_ptr(), dx.data_ptr(), ws.data_ptr(), ws.numel(), S()))
+    assert report(f"mrstft loss B={B} L={L_}", abs(loss.item() - want_loss) / want_loss, 1e-5)
+    got = dx.cpu().double() / 2.5
+    assert report(f"mrstft gradient rel-L2 B={B} L={L_}", ((got - want_grad).norm() / want_grad.norm()).item(), 1e-4)
+    assert report(f"mrstft gradient max B={B} L={L_}", ((got - want_grad).abs().max() / want_grad.abs().max()).item(), 1e-3)
+    # value only (d_x = NULL) and bitwise reproducibility of the gradient
+    loss2, dx2 = torch.zeros(1, device=DEV), torch.empty_like(xd)
+    _lib.check(L().svs_mrstft_loss_fwd_bwd(xd.data_ptr(), yd.data_ptr(), B, L_, 2.5, loss2.data_ptr(), dx2.data_ptr(), ws.data_ptr(), ws.numel(), S()))
+    assert torch.equal(dx, dx2) and loss.item() == loss2.item()

@@ -488,3 +488,41 @@ def test_eval_cache_follows_every_kind_of_weight_change(report):
         m3 = model(x).cpu()
         assert report("eval after train-mode forward vs oracle", (m3 - oracle_mask()).abs().max().item(), 1e-4)
         assert (m3 - m2).abs().max().item() > 1e-5
+
+
+def test_train_step_full_objective(report):
+    """The reference's full objective (train.py:274-299): alpha_L1 * L1 + alpha_MR * MR-STFT of the re-synthesised
+    waveforms, through UNet.fwd_bwd with the phase tiles, against the float64 oracle (unet_oracle + stft / mrstft oracles
+    with autograd): both loss parts and every parameter gradient."""
+    from oracle import mrstft_oracle as mo
+    B = 2
+    mix_np, voc_np = synth.tiles(B, first_tile=800)
+    mph = (synth.uniform(30, B * 512 * 128) * 2 * np.pi - np.pi).astype(np.float32).reshape(B, 1, 512, 128)
+    vph = (synth.uniform(31, B * 512 * 128) * 2 * np.pi - np.pi).astype(np.float32).reshape(B, 1, 512, 128)
+    fresh = synth.closed_form_state(trained_stats=False)
+    masks_np = synth.dropout_masks(B, seed=5, step=0)
+    st = uo.to_torch_state(fresh, torch.float64)
+    l1_o, mr_o, grads_o = mo.train_grads_full(st, torch.from_numpy(mix_np).double(), torch.from_numpy(voc_np).double(),
+                                              torch.from_numpy(mph).double(), torch.from_numpy(vph).double(),
+                                              dropout_masks=[torch.from_numpy(m).double() for m in masks_np])
+    model = make_model(trained_stats=False).train()
+    model.set_dropout_masks([torch.from_numpy(m) for m in masks_np])
+    model.optim.zero_grad()
+    to = lambda a: torch.from_numpy(a).to(DEV)
+    l1 = model.fwd_bwd(to(mix_np), to(voc_np), loss_scale=mo.ALPHA_L1, mix_phase=to(mph), voc_phase=to(vph), alpha_mr=mo.ALPHA_MR)
+    assert report("full objective: L1 part", abs(l1.item() - l1_o) / l1_o, 1e-5)
+    assert report("full objective: MR-STFT part", abs(model.last_mr_loss.item() - mr_o) / mr_o, 1e-4)
+    fused = _grads_by_name(model)
+    for n, gw in grads_o.items():
+        if n.endswith(".0.bias") and n.startswith("conv") or (n.startswith("deconv") and n.endswith(".bias") and "BAD" not in n and n != "deconv6.bias"):
+            continue                                    # bias in front of a BatchNorm: true gradient 0
+        e = (fused[n] - gw).norm().item() / max(gw.norm().item(), 1e-12)
+        assert report(f"full objective grad {n} rel-L2", e, 2e-2)
+    # the MR term really contributes: gradients differ from the L1-only step
+    model2 = make_model(trained_stats=False).train()
+    model2.set_dropout_masks([torch.from_numpy(m) for m in masks_np])
+    model2.optim.zero_grad()
+    model2.fwd_bwd(to(mix_np), to(voc_np), loss_scale=mo.ALPHA_L1)
+    assert model2.last_mr_loss is None
+    d = (model2._gflat - model._gflat).norm().item() / model._gflat.norm().item()
+    assert d > 1e-3, d
