@@ -282,11 +282,11 @@ int svs_stft_groups(int frames_alloc);
 /* svs_istft_tiles: y (channels, hop * (frames - 1)) = istft(mag [* mask or * (1 - mask)] * phase).  mask (optional, same
  *   layout as mag) fuses inference.py:100-107.  phase_mode 1: frame-major phasors; 3: angles in the layout of mag
  *   (train.py:33-60, `specific_istft`: the DC row that train.py:41-42 pads back is the absent first_bin row).
- *   n_fft / 2 <= hop <= n_fft.  absmax_partial (optional): channels * svs_istft_groups(hop, frames) maxima of |y|. */
+ *   n_fft / 2 <= hop <= n_fft.  absmax_partial (optional): [channels][svs_istft_groups(hop, frames, channels)] maxima of |y|. */
 int svs_istft_tiles(const float* mag, int64_t chan_stride, int seg, int rows, int first_bin, const float* mask, int invert,
                     const float* phase, int phase_mode, int channels, int n_fft, int hop, int frames, float* y,
                     float* absmax_partial, hipStream_t stream);
-int svs_istft_groups(int hop, int frames);
+int svs_istft_groups(int hop, int frames, int channels);
 /* (rows, cols) complex64 -> (cols, rows): f-major phasor files <-> the frame-major form */
 int svs_transpose_c64(const float* in, float* out, int rows, int cols, hipStream_t stream);
 /* Backward of `specific_istft` (train.py:33-60) fused with the chain rule of |S| = mask * mix (train.py:275,288):

@@ -82,7 +82,7 @@ _SIGS = {
     "svs_stft_tiles": (I, [P, L, I, I, I, P, L, I, I, I, I, P, I, P, P]),
     "svs_stft_groups": (I, [I]),
     "svs_istft_tiles": (I, [P, L, I, I, I, P, I, P, I, I, I, I, I, P, P, P]),
-    "svs_istft_groups": (I, [I, I]),
+    "svs_istft_groups": (I, [I, I, I]),
     "svs_transpose_c64": (I, [P, P, I, I, P]),
     "svs_istft_bwd_mask": (I, [P, P, P, P, P, F, I, I, I, I, P]),
     "svs_mrstft_workspace_bytes": (Z, [I, L]),

@@ -24,9 +24,9 @@
 
 #define NFFT 1024
 #define NBIN 513
-#define GROUP 16                  // frames (hops) per block
-#define SROW (GROUP + 1)          // floats per staged row (17: odd -> conflict-free column access)
-#define IROW 19                   // inverse: 17 frames per row, odd pitch
+#define GROUP 16                  // forward: frames per block (8 waves x 2)
+#define SROW (GROUP + 1)          // floats per staged angle row (odd -> conflict-free column access)
+#define IGROUP 15                 // inverse: hops per step; they touch 16 frames = 8 waves x 2 (one of 16 transforms is halo)
 
 // Address of (channel c, bin k, frame t) of an f-major spectrogram cut into `seg`-frame tiles of `rows` rows each,
 // the first of which is bin `first_bin`:  (513, T) file: seg = T, rows = 513, first_bin = 0;
@@ -42,15 +42,21 @@ struct SpecLayout {
 __device__ __forceinline__ float hann_at(int m) { return 0.5f - 0.5f * cospif((float)m * (2.0f / NFFT)); }
 
 // window sum-of-squares at padded position q (= sample index + n_fft/2) for T frames of hop `hop`
-__device__ __forceinline__ float envelope_at(long q, int hop, int T, const float* win) {
+__device__ __forceinline__ float envelope_at(long q, int hop, int T) {
   long t1 = q / hop;
   if (t1 > T - 1) t1 = T - 1;
   long t0 = q - (NFFT - 1);
   t0 = t0 <= 0 ? 0 : (t0 + hop - 1) / hop;
   float env = 0.f;
-  for (long t = t0; t <= t1; ++t) { const float w = win[q - t * hop]; env += w * w; }
+  for (long t = t0; t <= t1; ++t) { const float w = hann_at((int)(q - t * hop)); env += w * w; }
   return env;
 }
+
+// The transposes between "a frame = a column" (what a transform works on) and "a row = consecutive frames" (what HBM
+// holds) go through the waves' own FFT buffers: wave w keeps the two values (frame 2w, frame 2w+1) of bin k as ONE
+// float2 at raw element k + w of its buffer (the + w skews the waves by one bank pair, so the 16 values of a row -- two
+// from each of the 8 buffers, BUF * 2 floats apart = 0 mod 32 banks -- come from 16 different banks).
+__device__ __forceinline__ int xpose_at(int wave, int k) { return wave * FftSize<NFFT>::BUF + k + wave; }
 
 // ------------------------------------------------------------------------------------------------
 // forward: frames of a real signal -> bins
@@ -72,122 +78,125 @@ __global__ __launch_bounds__(512) void stft_fwd_kernel(StftArgs p) {
   constexpr int BUF = FftSize<NFFT>::BUF, TW = FftSize<NFFT>::TW;
   float2* const fbuf = (float2*)smem;                       // [8][BUF]
   float2* const tw = fbuf + 8 * BUF;                        // [TW]
-  float* const win = (float*)(tw + TW);                     // [NFFT]
-  float* const stage = win + NFFT;                          // [513 * 9 * 2] (>= 513 * 17)
-  float* const angs = stage + NBIN * 18;                    // SINK_DMAG only: [513 * 17]
+  float* const angs = (float*)(tw + TW);                    // SINK_DMAG only: [513 * 17]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = blockIdx.y, t0 = blockIdx.x * GROUP;
   fft_build_twiddles<NFFT>(tw, tid, 512);
-  for (int m = tid; m < NFFT; m += 512) win[m] = hann_at(m);
   if (SINK == SINK_DMAG) {
     for (int e = tid; e < NBIN * GROUP; e += 512) {
       const int k = e / GROUP, col = e - k * GROUP, t = t0 + col;
       angs[k * SROW + col] = (k >= p.lay.first_bin && t < p.T) ? p.angle[p.lay.at(c, k, t)] : 0.f;
     }
   }
-  __syncthreads();
   float2* const buf = fbuf + wave * BUF;
   const int ta = t0 + 2 * wave, tb = ta + 1;
-  // ---- frames ta, tb -> z = a + i b (windowed)
-#pragma unroll 4
-  for (int r = 0; r < NFFT / 64; ++r) {
-    const int m = lane + 64 * r;
-    float v[2];
+  // ---- frames ta, tb -> z = a + i b (windowed); 4 consecutive samples per lane and step
+  const float* ysig = p.y + (long)c * p.n_samples;
+  const bool vec_ok = ((p.n_samples | p.hop) & 3) == 0 && ((uintptr_t)p.y & 15u) == 0;
+#pragma unroll
+  for (int r = 0; r < NFFT / 256; ++r) {
+    const int m0 = 4 * lane + 256 * r;
+    float v[2][4];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int t = ta + h;
-      const long q = (long)t * p.hop + m;                 // padded position; sample index = q - NFFT/2
-      const long s = q - NFFT / 2;
-      float x = 0.f;
-      if (t < p.T && s >= 0 && s < p.n_samples) {
-        x = p.y[(long)c * p.n_samples + s];
-        if (SRC == SRC_ENVDIV) {
-          const float env = envelope_at(q, p.hop, p.T, win);
-          if (env > 1.1754944e-38f) x /= env;
-        }
+      const long q0 = (long)t * p.hop + m0, s0 = q0 - NFFT / 2;
+      if (t < p.T && vec_ok && s0 >= 0 && s0 + 3 < p.n_samples) {
+        const f32x4 x = *(const f32x4*)(ysig + s0);
+        v[h][0] = x[0]; v[h][1] = x[1]; v[h][2] = x[2]; v[h][3] = x[3];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const long s = s0 + j; v[h][j] = (t < p.T && s >= 0 && s < p.n_samples) ? ysig[s] : 0.f; }
       }
-      v[h] = x * win[m];
+      if (SRC == SRC_ENVDIV) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float env = envelope_at(q0 + j, p.hop, p.T); if (env > 1.1754944e-38f) v[h][j] /= env; }
+      }
     }
-    buf[fft_pad(m)] = float2{v[0], v[1]};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const float w = hann_at(m0 + j); buf[fft_pad(m0 + j)] = float2{v[0][j] * w, v[1][j] * w}; }
   }
+  __syncthreads();                                          // twiddles (and staged angles) are complete
   fft_wave<NFFT>(buf, tw, lane);
-  // ---- separate the two spectra, bins k = 0 .. 512
+  // ---- separate the two spectra, bins k = 0 .. 512, into registers (every Z is read before the buffer is reused)
+  float2 A[9], B[9];
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    const int k = lane + 64 * r;
+    A[r] = B[r] = float2{0.f, 0.f};
+    if (k > NFFT / 2) continue;
+    const float2 zk = buf[fft_pad(k)], zn = buf[fft_pad((NFFT - k) & (NFFT - 1))];
+    A[r] = float2{0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y)};
+    B[r] = float2{0.5f * (zk.y + zn.y), 0.5f * (zn.x - zk.x)};
+  }
   float vmax = 0.f;
 #pragma unroll
   for (int r = 0; r < 9; ++r) {
     const int k = lane + 64 * r;
     if (k > NFFT / 2) continue;
-    const float2 zk = buf[fft_pad(k)], zn = buf[fft_pad((NFFT - k) & (NFFT - 1))];
-    const float2 A = float2{0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y)};
-    const float2 B = float2{0.5f * (zk.y + zn.y), 0.5f * (zn.x - zk.x)};
+    float2 out;
     if (SINK == SINK_MAGPHASE) {
-      const float ma = sqrtf(A.x * A.x + A.y * A.y), mb = sqrtf(B.x * B.x + B.y * B.y);
-      stage[k * SROW + 2 * wave] = ma;
-      stage[k * SROW + 2 * wave + 1] = mb;
+      const float ma = sqrtf(A[r].x * A[r].x + A[r].y * A[r].y), mb = sqrtf(B[r].x * B[r].x + B[r].y * B[r].y);
+      out = float2{ma, mb};
       if (ta < p.T) vmax = fmaxf(vmax, ma);
       if (tb < p.T) vmax = fmaxf(vmax, mb);
       if (p.phase_mode == 1) {                             // unit phasors, 1 + 0i where the bin is exactly zero (librosa.magphase)
         float2* ph = (float2*)p.phase;
-        if (ta < p.T) ph[((long)c * p.T + ta) * NBIN + k] = ma == 0.f ? float2{1.f, 0.f} : float2{A.x / ma, A.y / ma};
-        if (tb < p.T) ph[((long)c * p.T + tb) * NBIN + k] = mb == 0.f ? float2{1.f, 0.f} : float2{B.x / mb, B.y / mb};
+        if (ta < p.T) ph[((long)c * p.T + ta) * NBIN + k] = ma == 0.f ? float2{1.f, 0.f} : float2{A[r].x / ma, A[r].y / ma};
+        if (tb < p.T) ph[((long)c * p.T + tb) * NBIN + k] = mb == 0.f ? float2{1.f, 0.f} : float2{B[r].x / mb, B[r].y / mb};
       }
     } else {
       // transpose of irfft (1/N, bins 1..511 count twice, imaginary parts of DC / Nyquist are ignored by irfft), then
       // d|S| = Re(conj(e^{i phi}) G)
-      const float ck = (k == 0 || k == NFFT / 2) ? 1.0f / NFFT : 2.0f / NFFT;
+      const bool edge = (k == 0 || k == NFFT / 2);
+      const float ck = edge ? 1.0f / NFFT : 2.0f / NFFT;
       float sa, ca, sb, cb;
       sincosf(angs[k * SROW + 2 * wave], &sa, &ca);
       sincosf(angs[k * SROW + 2 * wave + 1], &sb, &cb);
-      const bool edge = (k == 0 || k == NFFT / 2);
-      stage[k * SROW + 2 * wave] = ck * (A.x * ca + (edge ? 0.f : A.y * sa));
-      stage[k * SROW + 2 * wave + 1] = ck * (B.x * cb + (edge ? 0.f : B.y * sb));
+      out = float2{ck * (A[r].x * ca + (edge ? 0.f : A[r].y * sa)), ck * (B[r].x * cb + (edge ? 0.f : B[r].y * sb))};
     }
+    fbuf[xpose_at(wave, k)] = out;
   }
   __syncthreads();
   // ---- rows out: 16 consecutive frames of a bin = one 64-byte run
+  const float* const xp = (const float*)fbuf;
   for (int e = tid; e < NBIN * GROUP; e += 512) {
     const int k = e / GROUP, col = e - k * GROUP, t = t0 + col;
     if (k < p.lay.first_bin || t >= p.lay.frames_alloc) continue;
-    const float v = t < p.T ? stage[k * SROW + col] : 0.f;       // tile padding beyond the last frame is written as zeros
+    const float v = t < p.T ? xp[2 * xpose_at(col >> 1, k) + (col & 1)] : 0.f;       // tile padding beyond the last frame is written as zeros
     const long idx = p.lay.at(c, k, t);
     if (SINK == SINK_MAGPHASE) p.mag[idx] = v;
     else if (t < p.T) { const float m = p.mask[idx]; p.d_logit[idx] += p.alpha * v * p.mix[idx] * m * (1.f - m); }
   }
   if (SINK == SINK_MAGPHASE && p.phase_mode == 2) {
-    // f-major phasors (the .npy layout of data.py:108-109): two more staged rounds of 8 frames each, as float2
-    float2* const st2 = (float2*)stage;                     // [513][9]
-    float2* ph = (float2*)p.phase;
-    for (int half = 0; half < 2; ++half) {
-      __syncthreads();
-      if ((wave >> 2) == half) {
+    // f-major phasors (the .npy layout of data.py:108-109): a second transposed round, phasor of frame 2w at raw
+    // element k + w, of frame 2w+1 at 544 + k + w of the wave's buffer
+    __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 9; ++r) {
-          const int k = lane + 64 * r;
-          if (k > NFFT / 2) continue;
-          const float2 zk = buf[fft_pad(k)], zn = buf[fft_pad((NFFT - k) & (NFFT - 1))];
-          const float2 A = float2{0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y)};
-          const float2 B = float2{0.5f * (zk.y + zn.y), 0.5f * (zn.x - zk.x)};
-          const float ma = sqrtf(A.x * A.x + A.y * A.y), mb = sqrtf(B.x * B.x + B.y * B.y);
-          st2[k * 9 + 2 * (wave & 3)] = ma == 0.f ? float2{1.f, 0.f} : float2{A.x / ma, A.y / ma};
-          st2[k * 9 + 2 * (wave & 3) + 1] = mb == 0.f ? float2{1.f, 0.f} : float2{B.x / mb, B.y / mb};
-        }
-      }
-      __syncthreads();
-      for (int e = tid; e < NBIN * 8; e += 512) {
-        const int k = e >> 3, col = e & 7, t = t0 + 8 * half + col;
-        if (t < p.T) ph[((long)c * NBIN + k) * p.T + t] = st2[k * 9 + col];
-      }
+    for (int r = 0; r < 9; ++r) {
+      const int k = lane + 64 * r;
+      if (k > NFFT / 2) continue;
+      const float ma = sqrtf(A[r].x * A[r].x + A[r].y * A[r].y), mb = sqrtf(B[r].x * B[r].x + B[r].y * B[r].y);
+      fbuf[xpose_at(wave, k)] = ma == 0.f ? float2{1.f, 0.f} : float2{A[r].x / ma, A[r].y / ma};
+      fbuf[xpose_at(wave, k) + 544] = mb == 0.f ? float2{1.f, 0.f} : float2{B[r].x / mb, B[r].y / mb};
+    }
+    __syncthreads();
+    float2* ph = (float2*)p.phase;
+    for (int e = tid; e < NBIN * GROUP; e += 512) {
+      const int k = e / GROUP, col = e - k * GROUP, t = t0 + col;
+      if (t < p.T) ph[((long)c * NBIN + k) * p.T + t] = fbuf[xpose_at(col >> 1, k) + 544 * (col & 1)];
     }
   }
   if (p.absmax_partial) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
     __syncthreads();
-    if (lane == 0) stage[wave] = vmax;
+    float* red = (float*)fbuf;
+    if (lane == 0) red[wave] = vmax;
     __syncthreads();
     if (tid == 0) {
-      float m = stage[0];
-      for (int w = 1; w < 8; ++w) m = fmaxf(m, stage[w]);
+      float m = red[0];
+      for (int w = 1; w < 8; ++w) m = fmaxf(m, red[w]);
       p.absmax_partial[(long)blockIdx.y * gridDim.x + blockIdx.x] = m;
     }
   }
@@ -205,120 +214,164 @@ struct IstftArgs {
   float* absmax_partial;
 };
 
-__global__ __launch_bounds__(512) void istft_kernel(IstftArgs p) {
+// A 512-thread block (8 waves) owns, per step, the padded samples [hop * t0, hop * (t0 + 15)) of one channel: exactly the 16
+// frames t0-1 .. t0+14 touch them (hop >= n_fft / 2), two per wave (nine waves / 17 hops would cap the kernel at 168
+// VGPRs -- three waves on one SIMD -- and spill the prefetch registers).  Inputs are transposed into the waves' buffers
+// (magnitudes as raw floats 2(k + w) + (f & 1), angles 1088 floats higher), each wave builds the Hermitian spectrum of
+// Sa + i Sb, transforms, and the output threads add the two frames that cover a sample straight from the buffers.
+// Blocks are persistent (grid = one per CU) and software-pipelined: the magnitudes / masks / phasors of the NEXT group
+// are loaded into registers while the current group is transformed and written, so the HBM latency of the ~16 dependent-free
+// loads per thread is paid once per block, not once per group (the one-group-per-block form ran at 1.0 TB/s).
+template <int PMODE>                                        // phase_mode as a template argument: only its prefetch registers exist
+__global__ __launch_bounds__(512) void istft_kernel(IstftArgs p, int ngroups) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int BUF = FftSize<NFFT>::BUF, TW = FftSize<NFFT>::TW;
+  constexpr int BUF = FftSize<NFFT>::BUF, TW = FftSize<NFFT>::TW, NW = 8, NF = 2 * NW;
+  constexpr int NIT = (NBIN * NF + 511) / 512;              // staged values per thread and group (17: 513 * 16 / 512)
   float2* const fbuf = (float2*)smem;                       // [8][BUF]
-  float2* const tw = fbuf + 8 * BUF;
-  float* const win = (float*)(tw + TW);
-  float* const mags = win + NFFT;                           // [513 * 19]; later the overlap-add buffer [16 * hop <= 16 * 1024]
-  float* const angs = mags + NBIN * IROW;                   // [513 * 19] (phase_mode 3)
-  float* const ola = mags;
+  float2* const tw = fbuf + NW * BUF;
+  float* const win = (float*)(tw + TW);                     // [NFFT]
+  float* const raw = (float*)fbuf;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int c = blockIdx.y, t0 = blockIdx.x * GROUP;        // owns padded samples [hop * t0, hop * (t0 + 16)): frames t0-1 .. t0+15
-  const int NF = GROUP + 1;
+  const int total = ngroups * p.channels;
   fft_build_twiddles<NFFT>(tw, tid, 512);
   for (int m = tid; m < NFFT; m += 512) win[m] = hann_at(m);
-  for (int e = tid; e < NBIN * NF; e += 512) {
-    const int k = e / NF, f = e - k * NF, t = t0 - 1 + f;
-    float m = 0.f, a = 0.f;
-    if (k >= p.lay.first_bin && t >= 0 && t < p.T) {
-      const long idx = p.lay.at(c, k, t);
-      m = p.mag[idx];
-      if (p.mask) { const float mk = p.mask[idx]; m *= p.invert ? 1.f - mk : mk; }
-      if (p.phase_mode == 3) a = p.phase[idx];
-    }
-    mags[k * IROW + f] = m;
-    if (p.phase_mode == 3) angs[k * IROW + f] = a;
-  }
-  __syncthreads();
   float2* const buf = fbuf + wave * BUF;
-  // spectrum value of local frame f, bin k (imaginary parts of DC / Nyquist dropped, as irfft does)
-  auto spec = [&](int f, int k) -> float2 {
-    const int t = t0 - 1 + f;
-    const float m = mags[k * IROW + f];
-    float2 s;
-    if (p.phase_mode == 3) { float sn, cs; sincosf(angs[k * IROW + f], &sn, &cs); s = float2{m * cs, m * sn}; }
-    else if (t >= 0 && t < p.T) { const float2 ph = ((const float2*)p.phase)[((long)c * p.T + t) * NBIN + k]; s = float2{m * ph.x, m * ph.y}; }
-    else s = float2{0.f, 0.f};
-    if (k == 0 || k == NFFT / 2) s.y = 0.f;
-    return s;
-  };
-  // conj(Z) with Z = Sa + i Sb (Hermitian-extended): the forward transform of conj(Z) is conj(ifft(Z)) = a - i b
-  auto build = [&](int fa, bool has_b) {
+  const float2* const ph = (const float2*)p.phase;
+
+  float sm[NIT], sa[PMODE == 3 ? NIT : 1];                  // staged magnitudes (x mask) / angles of the next group
+  float2 pa[PMODE == 1 ? 9 : 1], pb[PMODE == 1 ? 9 : 1];    // phasors of this wave's two frames of the next group (mode 1)
+  // 32-bit byte offsets into buffer descriptors (one VGPR per address in flight instead of two; the host checks that the
+  // views stay below 2 GiB); an out-of-range element is pointed past num_records and reads as zero
+  constexpr unsigned OOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t rmag = __builtin_amdgcn_make_buffer_rsrc((void*)p.mag, 0, OOB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rmask = __builtin_amdgcn_make_buffer_rsrc((void*)(p.mask ? p.mask : p.mag), 0, OOB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rph = __builtin_amdgcn_make_buffer_rsrc((void*)p.phase, 0, OOB, 0x00020000);
+  const bool has_mask = p.mask != nullptr;
+  auto fetch = [&](int g) {
+    const int c = g / ngroups, t0 = (g - c * ngroups) * IGROUP;
 #pragma unroll
-    for (int r = 0; r < 9; ++r) {
-      const int k = lane + 64 * r;
-      if (k > NFFT / 2) continue;
-      const float2 sa = spec(fa, k);
-      const float2 sb = has_b ? spec(fa + 1, k) : float2{0.f, 0.f};
-      buf[fft_pad(k)] = float2{sa.x - sb.y, -(sa.y + sb.x)};
-      if (k > 0 && k < NFFT / 2) buf[fft_pad(NFFT - k)] = float2{sa.x + sb.y, -(sb.x - sa.y)};
+    for (int it = 0; it < NIT; ++it) {
+      const int e = tid + 512 * it;
+      const int k = e / NF, f = e - k * NF, t = t0 - 1 + f;
+      const bool ok = e < NBIN * NF && k >= p.lay.first_bin && t >= 0 && t < p.T;
+      const unsigned off = ok ? (unsigned)p.lay.at(c, k, t) * 4u : OOB;
+      float m = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rmag, (int)off, 0, 0));
+      if (has_mask) {
+        const float mk = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rmask, (int)off, 0, 0));
+        m *= p.invert ? 1.f - mk : mk;
+      }
+      sm[it] = m;
+      if (PMODE == 3) sa[PMODE == 3 ? it : 0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rph, (int)off, 0, 0));
     }
-  };
-  build(2 * wave, true);
-  // wave 0 also owns the 17th frame (local f = 16): its inputs are fetched now, before the staging area becomes the
-  // overlap-add buffer
-  float2 extra[9];
-  if (wave == 0) {
+    if (PMODE == 1) {
+      const int ta = t0 - 1 + 2 * wave;
+      struct F2 { float x, y; };                          // (bit_cast: whatever 8-byte type the builtin returns)
 #pragma unroll
-    for (int r = 0; r < 9; ++r) { const int k = lane + 64 * r; extra[r] = k <= NFFT / 2 ? spec(GROUP, k) : float2{0.f, 0.f}; }
-  }
-  fft_wave<NFFT>(buf, tw, lane);
-  __syncthreads();                                          // every wave is done with the staged inputs
-  const int span = GROUP * p.hop;
-  for (int e = tid; e < span; e += 512) ola[e] = 0.f;
-  __syncthreads();
-  auto add_frame = [&](int f, bool imag) {                  // rel = hop * (f - 1) + m
-    const int base = p.hop * (f - 1);
-#pragma unroll 4
-    for (int r = 0; r < NFFT / 64; ++r) {
-      const int m = lane + 64 * r, rel = base + m;
-      if (rel >= 0 && rel < span) {
-        const float2 z = buf[fft_pad(m)];
-        ola[rel] += (imag ? -z.y : z.x) * (win[m] * (1.0f / NFFT));
+      for (int r = 0; r < 9; ++r) {
+        const int k = lane + 64 * r;
+        const bool oka = k <= NFFT / 2 && ta >= 0 && ta < p.T, okb = k <= NFFT / 2 && ta + 1 >= 0 && ta + 1 < p.T;
+        const unsigned oa = oka ? (unsigned)(((long)c * p.T + ta) * NBIN + k) * 8u : OOB;
+        const unsigned ob = okb ? (unsigned)(((long)c * p.T + ta + 1) * NBIN + k) * 8u : OOB;
+        const F2 va = __builtin_bit_cast(F2, __builtin_amdgcn_raw_buffer_load_b64(rph, (int)oa, 0, 0));
+        const F2 vb = __builtin_bit_cast(F2, __builtin_amdgcn_raw_buffer_load_b64(rph, (int)ob, 0, 0));
+        pa[PMODE == 1 ? r : 0] = float2{va.x, va.y};
+        pb[PMODE == 1 ? r : 0] = float2{vb.x, vb.y};
       }
     }
   };
-  add_frame(2 * wave, false);                               // even local frames: pairwise disjoint
-  __syncthreads();
-  add_frame(2 * wave + 1, true);                            // odd local frames
-  __syncthreads();
-  if (wave == 0) {
+  int g = blockIdx.x;
+  if (g < total) fetch(g);
+  float vmax = 0.f;
+  int c_cur = g < total ? g / ngroups : 0;
+  // per-channel |y| maxima: partial[c][block]; a block's groups come channel by channel, so it flushes on a channel change
+  auto flush_max = [&](int c) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+    __syncthreads();
+    if (lane == 0) win[wave] = vmax;                        // (the window table is rebuilt below)
+    __syncthreads();
+    if (tid == 0) {
+      float m = win[0];
+      for (int w = 1; w < NW; ++w) m = fmaxf(m, win[w]);
+      p.absmax_partial[(long)c * gridDim.x + blockIdx.x] = m;
+    }
+    __syncthreads();
+    for (int m = tid; m < NW; m += 512) win[m] = hann_at(m);
+    vmax = 0.f;
+  };
+  if (p.absmax_partial)
+    for (int c = tid; c < p.channels; c += 512) p.absmax_partial[(long)c * gridDim.x + blockIdx.x] = 0.f;
+  for (; g < total; g += gridDim.x) {
+    const int c = g / ngroups, t0 = (g - c * ngroups) * IGROUP;
+    if (p.absmax_partial && c != c_cur) { flush_max(c_cur); c_cur = c; }
+    __syncthreads();                                        // the previous group's output threads are done with the buffers (first pass: tables built)
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int e = tid + 512 * it;
+      if (e < NBIN * NF) {
+        const int k = e / NF, f = e - k * NF, w = f >> 1, at = 2 * (w * BUF + k + w) + (f & 1);
+        raw[at] = sm[it];
+        if (PMODE == 3) raw[at + BUF] = sa[PMODE == 3 ? it : 0];      // BUF floats = half a buffer higher
+      }
+    }
+    __syncthreads();
+    // spectra of this wave's two frames into registers (imaginary parts of DC / Nyquist dropped, as irfft does)
+    float2 Sa[9], Sb[9];
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+      const int k = lane + 64 * r;
+      Sa[r] = Sb[r] = float2{0.f, 0.f};
+      if (k > NFFT / 2) continue;
+      const float2 m = buf[k + wave];
+      float2 qa = pa[PMODE == 1 ? r : 0], qb = pb[PMODE == 1 ? r : 0];
+      if (PMODE == 3) {
+        const float2 a = buf[k + wave + BUF / 2];
+        sincosf(a.x, &qa.y, &qa.x);
+        sincosf(a.y, &qb.y, &qb.x);
+      }
+      const bool edge = (k == 0 || k == NFFT / 2);
+      Sa[r] = float2{m.x * qa.x, edge ? 0.f : m.x * qa.y};
+      Sb[r] = float2{m.y * qb.x, edge ? 0.f : m.y * qb.y};
+    }
+    // conj(Z) with Z = Sa + i Sb (Hermitian-extended): the forward transform of conj(Z) is conj(ifft(Z)) = a - i b
 #pragma unroll
     for (int r = 0; r < 9; ++r) {
       const int k = lane + 64 * r;
       if (k > NFFT / 2) continue;
-      buf[fft_pad(k)] = float2{extra[r].x, -extra[r].y};
-      if (k > 0 && k < NFFT / 2) buf[fft_pad(NFFT - k)] = float2{extra[r].x, extra[r].y};
+      buf[fft_pad(k)] = float2{Sa[r].x - Sb[r].y, -(Sa[r].y + Sb[r].x)};
+      if (k > 0 && k < NFFT / 2) buf[fft_pad(NFFT - k)] = float2{Sa[r].x + Sb[r].y, -(Sb[r].x - Sa[r].y)};
     }
     fft_wave<NFFT>(buf, tw, lane);
-    add_frame(GROUP, false);                                // overlaps only frame 15, which is complete
-  }
-  __syncthreads();
-  float vmax = 0.f;
-  for (int e = tid; e < span; e += 512) {
-    const long q = (long)p.hop * t0 + e;                    // padded position
-    const long i = q - NFFT / 2;
-    if (i < 0 || i >= p.n_out) continue;
-    const float env = envelope_at(q, p.hop, p.T, win);
-    const float s = ola[e];
-    const float v = env > 1.1754944e-38f ? s / env : s;
-    p.y[(long)c * p.n_out + i] = v;
-    vmax = fmaxf(vmax, fabsf(v));
-  }
-  if (p.absmax_partial) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+    if (g + (int)gridDim.x < total) fetch(g + gridDim.x);   // next group's inputs: in flight during the output pass (issued here,
+                                                            // after the transform, so that its registers are free)
     __syncthreads();
-    if (lane == 0) ola[wave] = vmax;
-    __syncthreads();
-    if (tid == 0) {
-      float m = ola[0];
-      for (int w = 1; w < 8; ++w) m = fmaxf(m, ola[w]);
-      p.absmax_partial[(long)blockIdx.y * gridDim.x + blockIdx.x] = m;
+    // ---- output: sample rel = hop * (f - 1) + m of local frame f; at most frames f_hi (m < hop) and f_hi - 1 (m + hop < n_fft)
+    const int span = IGROUP * p.hop;
+    for (int e = tid; e < span; e += 512) {
+      const long q = (long)p.hop * t0 + e;                  // padded position
+      const long i = q - NFFT / 2;
+      if (i < 0 || i >= p.n_out) continue;
+      const int fh = e / p.hop + 1, m = e - (fh - 1) * p.hop;
+      const float2 z1 = fbuf[(fh >> 1) * BUF + fft_pad(m)];
+      float s = ((fh & 1) ? -z1.y : z1.x) * win[m];         // (frames outside [0, T) hold zeros)
+      if (m + p.hop < NFFT) {
+        const float2 z0 = fbuf[((fh - 1) >> 1) * BUF + fft_pad(m + p.hop)];
+        s += (((fh - 1) & 1) ? -z0.y : z0.x) * win[m + p.hop];
+      }
+      s *= 1.0f / NFFT;
+      // window envelope: the frames t with hop t <= q < hop t + n_fft, 0 <= t < T (same rule as the frames above, global t)
+      long t1 = q / p.hop;
+      if (t1 > p.T - 1) t1 = p.T - 1;
+      long tl = q - (NFFT - 1);
+      tl = tl <= 0 ? 0 : (tl + p.hop - 1) / p.hop;
+      float env = 0.f;
+      for (long t = tl; t <= t1; ++t) { const float w = win[q - t * p.hop]; env += w * w; }
+      const float v = env > 1.1754944e-38f ? s / env : s;
+      p.y[(long)c * p.n_out + i] = v;
+      vmax = fmaxf(vmax, fabsf(v));
     }
   }
+  if (p.absmax_partial && blockIdx.x < total) flush_max(c_cur);
 }
 
 // (R, C) float2 matrix -> (C, R): f-major phasors of a .npy file <-> the frame-major form the kernels stream
@@ -339,13 +392,11 @@ __global__ __launch_bounds__(256) void transpose_c64_kernel(const float2* __rest
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-static size_t fwd_lds_bytes(bool dmag) {
-  return (size_t)8 * FftSize<NFFT>::BUF * 8 + FftSize<NFFT>::TW * 8 + NFFT * 4 + NBIN * 18 * 4 + (dmag ? NBIN * SROW * 4 : 0);
+static size_t fwd_lds_bytes(bool dmag) {       // 79,872 B: two blocks per CU
+  return (size_t)8 * FftSize<NFFT>::BUF * 8 + FftSize<NFFT>::TW * 8 + (dmag ? NBIN * SROW * 4 : 0);
 }
-static size_t inv_lds_bytes() {
-  const size_t stage = (size_t)NBIN * IROW * 4 * 2, olab = (size_t)GROUP * NFFT * 4;
-  return (size_t)8 * FftSize<NFFT>::BUF * 8 + FftSize<NFFT>::TW * 8 + NFFT * 4 + (stage > olab ? stage : olab);
-}
+static size_t inv_lds_bytes() { return (size_t)8 * FftSize<NFFT>::BUF * 8 + FftSize<NFFT>::TW * 8 + NFFT * 4; }
+#define ISTFT_MAX_BLOCKS 256      // persistent: one block (8 waves, 84 KB of LDS) per CU
 template <class K>
 static int allow_lds(K kernel, size_t bytes) {
   SVS_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
@@ -387,6 +438,14 @@ extern "C" int svs_stft_fwd(const float* y, int64_t n_samples, int n_fft, int ho
   return svs_stft_tiles(y, n_samples, 1, n_fft, hop, mag, (int64_t)NBIN * T, T, NBIN, 0, T, phase, phase ? 2 : 0, nullptr, stream);
 }
 
+// padded length n_fft + hop * (T - 1): the last samples belong to group floor((padded - 1) / (15 hop))
+static int svs_istft_groups_per_channel(int hop, int frames) { return (int)((NFFT + (long)hop * (frames - 1) + (long)IGROUP * hop - 1) / ((long)IGROUP * hop)); }
+// persistent blocks of svs_istft_tiles = absmax partials per channel (layout [channel][block])
+extern "C" int svs_istft_groups(int hop, int frames, int channels) {
+  const long total = (long)svs_istft_groups_per_channel(hop, frames) * channels;
+  return (int)(total < ISTFT_MAX_BLOCKS ? total : ISTFT_MAX_BLOCKS);
+}
+
 extern "C" int svs_istft_tiles(const float* mag, int64_t chan_stride, int seg, int rows, int first_bin, const float* mask, int invert,
                                const float* phase, int phase_mode, int channels, int n_fft, int hop, int frames, float* y,
                                float* absmax_partial, hipStream_t stream) {
@@ -394,6 +453,8 @@ extern "C" int svs_istft_tiles(const float* mag, int64_t chan_stride, int seg, i
   SVS_REQUIRE(n_fft == NFFT, "svs_istft_tiles: only n_fft=1024 (reference config.py:47) is built, got %d", n_fft);
   SVS_REQUIRE(hop <= NFFT && hop >= NFFT / 2, "svs_istft_tiles: hop %d outside [n_fft/2, n_fft] (a sample may be covered by at most two frames)", hop);
   SVS_REQUIRE(phase_mode == 1 || phase_mode == 3, "svs_istft_tiles: phase_mode must be 1 (frame-major phasors) or 3 (angles)");
+  SVS_REQUIRE((long)channels * (chan_stride > (long)frames * NBIN ? chan_stride : (long)frames * NBIN) * 8 < (1L << 31),
+              "svs_istft_tiles: a spectrogram view of more than 2 GiB needs 64-bit offsets; split the channels");
   int rc = check_layout("svs_istft_tiles", seg, rows, first_bin, frames, frames);
   if (rc) return rc;
   IstftArgs a{};
@@ -402,16 +463,15 @@ extern "C" int svs_istft_tiles(const float* mag, int64_t chan_stride, int seg, i
   a.channels = channels; a.T = frames; a.hop = hop; a.y = y; a.n_out = (long)hop * (frames - 1);
   a.absmax_partial = absmax_partial;
   const size_t lds = inv_lds_bytes();
-  if ((rc = allow_lds(istft_kernel, lds))) return rc;
-  // padded length n_fft + hop * (T - 1): the last samples belong to group floor((padded - 1) / (16 hop))
-  const long padded = NFFT + (long)hop * (frames - 1);
-  dim3 grid((unsigned)((padded + (long)GROUP * hop - 1) / ((long)GROUP * hop)), (unsigned)channels);
-  hipLaunchKernelGGL(istft_kernel, grid, dim3(512), lds, stream, a);
+  if ((rc = phase_mode == 1 ? allow_lds(istft_kernel<1>, lds) : allow_lds(istft_kernel<3>, lds))) return rc;
+  const int ngroups = svs_istft_groups_per_channel(hop, frames);
+  const long total = (long)ngroups * channels;
+  const dim3 grid((unsigned)(total < ISTFT_MAX_BLOCKS ? total : ISTFT_MAX_BLOCKS));
+  if (phase_mode == 1) hipLaunchKernelGGL(istft_kernel<1>, grid, dim3(512), lds, stream, a, ngroups);
+  else hipLaunchKernelGGL(istft_kernel<3>, grid, dim3(512), lds, stream, a, ngroups);
   SVS_CHECK_LAUNCH("istft");
   return SVS_OK;
 }
-extern "C" int svs_istft_groups(int hop, int frames) { return (int)((NFFT + (long)hop * (frames - 1) + (long)GROUP * hop - 1) / ((long)GROUP * hop)); }
-
 extern "C" size_t svs_istft_workspace_bytes(int n_fft, int hop, int frames) {
   (void)n_fft; (void)hop;
   return (size_t)frames * NBIN * 8 + 256;           // frame-major copy of f-major phasors

@@ -108,7 +108,7 @@ def istft_from_tiles(tiles: torch.Tensor, mask, phase_fm: torch.Tensor, frames: 
     C, n_tiles, _, rows, seg = tiles.shape
     ph = torch.view_as_real(phase_fm.contiguous()).contiguous()
     y = torch.empty((C, hop * (frames - 1)), dtype=torch.float32, device=tiles.device)
-    groups = int(L.svs_istft_groups(hop, frames))
+    groups = int(L.svs_istft_groups(hop, frames, C))
     part = torch.empty((C, groups), dtype=torch.float32, device=tiles.device) if peak is not None else None
     _lib.check(L.svs_istft_tiles(tiles.data_ptr(), n_tiles * rows * seg, seg, rows, 1, None if mask is None else mask.data_ptr(),
                                  1 if invert else 0, ph.data_ptr(), 1, C, n_fft, hop, frames, y.data_ptr(),

@@ -9,6 +9,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from oracle import stft_oracle as so
 from svs_unet_pytorch_amd import _lib, synth
 
 pytestmark = pytest.mark.gpu
@@ -663,15 +664,18 @@ def test_istft_bwd_mask(golden, report):
     d0 = synth.uniform(12, B * 512 * T).reshape(B, 1, 512, T) - 0.5
     d_logit = torch.from_numpy(d0.copy()).to(DEV)
     dw = torch.from_numpy(wgt.astype(np.float32)).to(DEV)
-    _lib.check(L().svs_istft_bwd_mask(dw.data_ptr(), torch.from_numpy(ang).to(DEV).data_ptr(), torch.from_numpy(mix).to(DEV).data_ptr(),
-                                      torch.from_numpy(mask).to(DEV).data_ptr(), d_logit.data_ptr(), 0.37, B, 1024, 768, T, S()))
+    ang_d, mix_d, mask_d = torch.from_numpy(ang).to(DEV), torch.from_numpy(mix).to(DEV), torch.from_numpy(mask).to(DEV)
+    _lib.check(L().svs_istft_bwd_mask(dw.data_ptr(), ang_d.data_ptr(), mix_d.data_ptr(), mask_d.data_ptr(), d_logit.data_ptr(), 0.37, B, 1024,
+                                      768, T, S()))
     dmag = so.specific_istft_adjoint(wgt, ang)                                   # pinned against the reference in the CPU suite
     want = d0 + 0.37 * dmag * mix * mask * (1 - mask)
     scale = np.abs(0.37 * dmag * mix * mask * (1 - mask)).max()
     assert report("istft_bwd_mask vs oracle adjoint", np.abs(d_logit.cpu().numpy() - want).max() / scale, 2e-5)
     # and directly against the reference's autograd numbers: rows 0..3 of tile 0
-    got_dmag = (d_logit.cpu().numpy() - d0)[0, 0, :4] / (0.37 * mix * mask * (1 - mask))[0, 0, :4]
-    assert report("istft_bwd_mask vs reference autograd (rows 0-3)", np.abs(got_dmag - g["dmag_tile0_rows"]).max() / np.abs(g["dmag_tile0_rows"]).max(), 2e-4)
+    den = (0.37 * mix * mask * (1 - mask))[0, 0, :4]
+    got_dmag = (d_logit.cpu().numpy() - d0)[0, 0, :4] / den
+    big = den > 0.02                                      # (dividing the fp32 "+=" back out amplifies its rounding where mix*m*(1-m) is tiny)
+    assert report("istft_bwd_mask vs reference autograd (rows 0-3)", np.abs(got_dmag - g["dmag_tile0_rows"])[big].max() / np.abs(g["dmag_tile0_rows"]).max(), 2e-4)
 
 
 @pytest.mark.parametrize("B,L_", [(2, 97536), (3, 20000)])
@@ -682,6 +686,13 @@ def test_mrstft_loss_and_gradient(B, L_, report):
     x = (synth.uniform(20, B * L_).reshape(B, L_) - 0.5) * 0.4
     y = x * 0.7 + (synth.uniform(21, B * L_).reshape(B, L_) - 0.5) * 0.2
     want_loss, want_grad = mo.mrstft_loss_and_grad(torch.from_numpy(x).double(), torch.from_numpy(y).double())
+    # fp32 noise scale: the log-magnitude term weighs every bin by 1/|X|^2, so the gradient is as accurate as the SMALL
+    # bins of an fp32 FFT are -- torch's own fp32 run deviates from its fp64 run by 2e-4 .. 8e-4 depending on the host's FFT
+    # library (measured on two CPUs).  The kernel transforms the predicted and the target frame in ONE complex FFT, so a
+    # bin's rounding error is relative to max(|X|, |Y|) rather than |X|: a few times torch's fp32 error, hence the 2e-3 floor
+    _, g32 = mo.mrstft_loss_and_grad(torch.from_numpy(x), torch.from_numpy(y))
+    noise_l2 = ((g32.double() - want_grad).norm() / want_grad.norm()).item()
+    noise_max = ((g32.double() - want_grad).abs().max() / want_grad.abs().max()).item()
     xd, yd = torch.from_numpy(x).to(DEV), torch.from_numpy(y).to(DEV)
     ws = ws_tensor(L().svs_mrstft_workspace_bytes(B, L_))
     loss = torch.zeros(1, device=DEV)
@@ -689,8 +700,8 @@ def test_mrstft_loss_and_gradient(B, L_, report):
     _lib.check(L().svs_mrstft_loss_fwd_bwd(xd.data_ptr(), yd.data_ptr(), B, L_, 2.5, loss.data_ptr(), dx.data_ptr(), ws.data_ptr(), ws.numel(), S()))
     assert report(f"mrstft loss B={B} L={L_}", abs(loss.item() - want_loss) / want_loss, 1e-5)
     got = dx.cpu().double() / 2.5
-    assert report(f"mrstft gradient rel-L2 B={B} L={L_}", ((got - want_grad).norm() / want_grad.norm()).item(), 1e-4)
-    assert report(f"mrstft gradient max B={B} L={L_}", ((got - want_grad).abs().max() / want_grad.abs().max()).item(), 1e-3)
+    assert report(f"mrstft gradient rel-L2 B={B} L={L_}", ((got - want_grad).norm() / want_grad.norm()).item(), max(6 * noise_l2, 2e-3))
+    assert report(f"mrstft gradient max B={B} L={L_}", ((got - want_grad).abs().max() / want_grad.abs().max()).item(), max(6 * noise_max, 3e-3))
     # value only (d_x = NULL) and bitwise reproducibility of the gradient
     loss2, dx2 = torch.zeros(1, device=DEV), torch.empty_like(xd)
     _lib.check(L().svs_mrstft_loss_fwd_bwd(xd.data_ptr(), yd.data_ptr(), B, L_, 2.5, loss2.data_ptr(), dx2.data_ptr(), ws.data_ptr(), ws.numel(), S()))

@@ -427,12 +427,17 @@ def test_train_step_b64_golden(golden, report):
     assert report("train B=64 loss vs reference fp64 (gate 1e-5)", abs(loss.item() - want) / want, 1e-5)
     grads = _grads_by_name(model)
     gn64, gn32 = g["f64.grad_norm"], g["f32.grad_norm"]
+    total64 = float(np.sqrt((gn64 ** 2).sum()))
+    total = float(np.sqrt(sum(grads[n].norm().item() ** 2 for n in names)))
+    assert report("train B=64 global gradient norm (gate 1e-4)", abs(total - total64) / total64, 1e-4)
     for i, n in enumerate(names):
         got = grads[n].norm().item()
         noise = max(abs(gn32[i] - gn64[i]), 1e-4 * gn64[i], 2e-6)
         assert report(f"train B=64 |grad| {n}", abs(got - gn64[i]) / noise, 20.0), (n, got, gn64[i], gn32[i])
         if gn64[i] > 1e-6:
-            gate = max(1e-4, abs(gn32[i] - gn64[i]) / gn64[i])
+            # SURVEY 8(d) gate 1e-4 per tensor, or 3x the reference's own fp32 deviation, with an absolute floor of 1e-6 of
+            # the global gradient norm for the near-zero tensors (BatchNorm shifts deep in the encoder: |g| ~ 1e-4)
+            gate = max(1e-4, 3 * abs(gn32[i] - gn64[i]) / gn64[i], 1e-6 * total64 / gn64[i])
             assert report(f"train B=64 |grad| rel {n} (gate 1e-4)", abs(got - gn64[i]) / gn64[i], gate)
         f = grads[n].reshape(-1)
         stp = max(f.numel() // 64, 1)
