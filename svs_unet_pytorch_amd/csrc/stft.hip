@@ -37,9 +37,24 @@ struct SpecLayout {
     const int tile = t / seg;
     return (long)c * chan_stride + ((long)tile * rows + (k - first_bin)) * seg + (t - tile * seg);
   }
+  // the same as col(c, t) + k * seg: one division per (thread, group) instead of one per element
+  __device__ __forceinline__ long col(int c, int t) const {
+    const int tile = t / seg;
+    return (long)c * chan_stride + ((long)tile * rows - first_bin) * seg + (t - tile * seg);
+  }
 };
 
 __device__ __forceinline__ float hann_at(int m) { return 0.5f - 0.5f * cospif((float)m * (2.0f / NFFT)); }
+// the same value from the FFT's pass-2 twiddle table (tw2[256 + k] = exp(-2 pi i k / 1024), k < 256: exact sincospi
+// entries), by symmetry: an LDS read and three selects instead of a ~40-instruction cospif
+__device__ __forceinline__ float hann_tw(const float2* tw2, int m) {
+  const int r = m <= NFFT / 2 ? m : NFFT - m;
+  const float c = r < 256 ? tw2[256 + r].x : (r == 256 ? 0.f : -tw2[256 + (512 - r)].x);
+  return 0.5f - 0.5f * c;
+}
+// one-instruction form (v_cos_f32 takes revolutions; absolute error ~1e-6): used where the window also divides out again
+// (the inverse's overlap-add / envelope), not for the forward magnitudes
+__device__ __forceinline__ float hann_fast(int m) { return 0.5f - 0.5f * __builtin_amdgcn_cosf((float)m * (1.0f / NFFT)); }
 
 // window sum-of-squares at padded position q (= sample index + n_fft/2) for T frames of hop `hop`
 __device__ __forceinline__ float envelope_at(long q, int hop, int T) {
@@ -81,42 +96,48 @@ __global__ __launch_bounds__(512) void stft_fwd_kernel(StftArgs p) {
   float* const angs = (float*)(tw + TW);                    // SINK_DMAG only: [513 * 17]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = blockIdx.y, t0 = blockIdx.x * GROUP;
-  fft_build_twiddles<NFFT>(tw, tid, 512);
   if (SINK == SINK_DMAG) {
-    for (int e = tid; e < NBIN * GROUP; e += 512) {
-      const int k = e / GROUP, col = e - k * GROUP, t = t0 + col;
-      angs[k * SROW + col] = (k >= p.lay.first_bin && t < p.T) ? p.angle[p.lay.at(c, k, t)] : 0.f;
-    }
+    const int col = tid & (GROUP - 1), t = t0 + col;
+    const long cbase = t < p.T ? p.lay.col(c, t) : 0;
+    for (int k = tid >> 4; k < NBIN; k += 512 / GROUP)
+      angs[k * SROW + col] = (k >= p.lay.first_bin && t < p.T) ? p.angle[cbase + (long)k * p.lay.seg] : 0.f;
   }
   float2* const buf = fbuf + wave * BUF;
   const int ta = t0 + 2 * wave, tb = ta + 1;
-  // ---- frames ta, tb -> z = a + i b (windowed); 4 consecutive samples per lane and step
+  // ---- frames ta, tb -> z = a + i b (windowed); 4 consecutive samples per lane and step.  The loads are issued first and
+  // stay in flight while the twiddle table is built.
   const float* ysig = p.y + (long)c * p.n_samples;
   const bool vec_ok = ((p.n_samples | p.hop) & 3) == 0 && ((uintptr_t)p.y & 15u) == 0;
+  float v[NFFT / 256][2][4];
 #pragma unroll
   for (int r = 0; r < NFFT / 256; ++r) {
     const int m0 = 4 * lane + 256 * r;
-    float v[2][4];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int t = ta + h;
       const long q0 = (long)t * p.hop + m0, s0 = q0 - NFFT / 2;
       if (t < p.T && vec_ok && s0 >= 0 && s0 + 3 < p.n_samples) {
         const f32x4 x = *(const f32x4*)(ysig + s0);
-        v[h][0] = x[0]; v[h][1] = x[1]; v[h][2] = x[2]; v[h][3] = x[3];
+        v[r][h][0] = x[0]; v[r][h][1] = x[1]; v[r][h][2] = x[2]; v[r][h][3] = x[3];
       } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { const long s = s0 + j; v[h][j] = (t < p.T && s >= 0 && s < p.n_samples) ? ysig[s] : 0.f; }
+        for (int j = 0; j < 4; ++j) { const long s = s0 + j; v[r][h][j] = (t < p.T && s >= 0 && s < p.n_samples) ? ysig[s] : 0.f; }
       }
       if (SRC == SRC_ENVDIV) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { const float env = envelope_at(q0 + j, p.hop, p.T); if (env > 1.1754944e-38f) v[h][j] /= env; }
+        for (int j = 0; j < 4; ++j) { const float env = envelope_at(q0 + j, p.hop, p.T); if (env > 1.1754944e-38f) v[r][h][j] /= env; }
       }
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { const float w = hann_at(m0 + j); buf[fft_pad(m0 + j)] = float2{v[0][j] * w, v[1][j] * w}; }
   }
+  fft_build_twiddles<NFFT>(tw, tid, 512);
   __syncthreads();                                          // twiddles (and staged angles) are complete
+  const float2* const tw2 = tw + FftSize<NFFT>::TW1;
+#pragma unroll
+  for (int r = 0; r < NFFT / 256; ++r) {
+    const int m0 = 4 * lane + 256 * r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const float w = hann_tw(tw2, m0 + j); buf[fft_pad(m0 + j)] = float2{v[r][0][j] * w, v[r][1][j] * w}; }
+  }
   fft_wave<NFFT>(buf, tw, lane);
   // ---- separate the two spectra, bins k = 0 .. 512, into registers (every Z is read before the buffer is reused)
   float2 A[9], B[9];
@@ -136,14 +157,16 @@ __global__ __launch_bounds__(512) void stft_fwd_kernel(StftArgs p) {
     if (k > NFFT / 2) continue;
     float2 out;
     if (SINK == SINK_MAGPHASE) {
-      const float ma = sqrtf(A[r].x * A[r].x + A[r].y * A[r].y), mb = sqrtf(B[r].x * B[r].x + B[r].y * B[r].y);
+      // v_sqrt_f32 / v_rcp_f32 (1 ulp) instead of the ~12-instruction IEEE sequences: the kernel is VALU-issue-bound
+      const float ma = __builtin_amdgcn_sqrtf(A[r].x * A[r].x + A[r].y * A[r].y), mb = __builtin_amdgcn_sqrtf(B[r].x * B[r].x + B[r].y * B[r].y);
       out = float2{ma, mb};
       if (ta < p.T) vmax = fmaxf(vmax, ma);
       if (tb < p.T) vmax = fmaxf(vmax, mb);
       if (p.phase_mode == 1) {                             // unit phasors, 1 + 0i where the bin is exactly zero (librosa.magphase)
         float2* ph = (float2*)p.phase;
-        if (ta < p.T) ph[((long)c * p.T + ta) * NBIN + k] = ma == 0.f ? float2{1.f, 0.f} : float2{A[r].x / ma, A[r].y / ma};
-        if (tb < p.T) ph[((long)c * p.T + tb) * NBIN + k] = mb == 0.f ? float2{1.f, 0.f} : float2{B[r].x / mb, B[r].y / mb};
+        const float ia = __builtin_amdgcn_rcpf(ma), ib = __builtin_amdgcn_rcpf(mb);
+        if (ta < p.T) ph[((long)c * p.T + ta) * NBIN + k] = ma == 0.f ? float2{1.f, 0.f} : float2{A[r].x * ia, A[r].y * ia};
+        if (tb < p.T) ph[((long)c * p.T + tb) * NBIN + k] = mb == 0.f ? float2{1.f, 0.f} : float2{B[r].x * ib, B[r].y * ib};
       }
     } else {
       // transpose of irfft (1/N, bins 1..511 count twice, imaginary parts of DC / Nyquist are ignored by irfft), then
@@ -160,13 +183,18 @@ __global__ __launch_bounds__(512) void stft_fwd_kernel(StftArgs p) {
   __syncthreads();
   // ---- rows out: 16 consecutive frames of a bin = one 64-byte run
   const float* const xp = (const float*)fbuf;
-  for (int e = tid; e < NBIN * GROUP; e += 512) {
-    const int k = e / GROUP, col = e - k * GROUP, t = t0 + col;
-    if (k < p.lay.first_bin || t >= p.lay.frames_alloc) continue;
-    const float v = t < p.T ? xp[2 * xpose_at(col >> 1, k) + (col & 1)] : 0.f;       // tile padding beyond the last frame is written as zeros
-    const long idx = p.lay.at(c, k, t);
-    if (SINK == SINK_MAGPHASE) p.mag[idx] = v;
-    else if (t < p.T) { const float m = p.mask[idx]; p.d_logit[idx] += p.alpha * v * p.mix[idx] * m * (1.f - m); }
+  {
+    const int col = tid & (GROUP - 1), t = t0 + col;        // a thread keeps its frame: one tile division per thread
+    if (t < p.lay.frames_alloc) {
+      const long cbase = p.lay.col(c, t);
+      for (int k = tid >> 4; k < NBIN; k += 512 / GROUP) {
+        if (k < p.lay.first_bin) continue;
+        const float v = t < p.T ? xp[2 * xpose_at(col >> 1, k) + (col & 1)] : 0.f;   // tile padding beyond the last frame is written as zeros
+        const long idx = cbase + (long)k * p.lay.seg;
+        if (SINK == SINK_MAGPHASE) p.mag[idx] = v;
+        else if (t < p.T) { const float m = p.mask[idx]; p.d_logit[idx] += p.alpha * v * p.mix[idx] * m * (1.f - m); }
+      }
+    }
   }
   if (SINK == SINK_MAGPHASE && p.phase_mode == 2) {
     // f-major phasors (the .npy layout of data.py:108-109): a second transposed round, phasor of frame 2w at raw
@@ -214,47 +242,44 @@ struct IstftArgs {
   float* absmax_partial;
 };
 
-// A 512-thread block (8 waves) owns, per step, the padded samples [hop * t0, hop * (t0 + 15)) of one channel: exactly the 16
-// frames t0-1 .. t0+14 touch them (hop >= n_fft / 2), two per wave (nine waves / 17 hops would cap the kernel at 168
-// VGPRs -- three waves on one SIMD -- and spill the prefetch registers).  Inputs are transposed into the waves' buffers
-// (magnitudes as raw floats 2(k + w) + (f & 1), angles 1088 floats higher), each wave builds the Hermitian spectrum of
-// Sa + i Sb, transforms, and the output threads add the two frames that cover a sample straight from the buffers.
-// Blocks are persistent (grid = one per CU) and software-pipelined: the magnitudes / masks / phasors of the NEXT group
-// are loaded into registers while the current group is transformed and written, so the HBM latency of the ~16 dependent-free
-// loads per thread is paid once per block, not once per group (the one-group-per-block form ran at 1.0 TB/s).
-template <int PMODE>                                        // phase_mode as a template argument: only its prefetch registers exist
-__global__ __launch_bounds__(512) void istft_kernel(IstftArgs p, int ngroups) {
+// A 512-thread block (8 waves) owns the padded samples [hop * t0, hop * (t0 + 15)) of one channel: exactly the 16 frames
+// t0-1 .. t0+14 touch them (hop >= n_fft / 2), two per wave.  Inputs are transposed into the waves' buffers (magnitudes as
+// raw floats 2(k + w) + (f & 1), angles 1088 floats higher), each wave builds the Hermitian spectrum of Sa + i Sb,
+// transforms, and the output threads add the (at most two) frames that cover a sample straight from the buffers and divide
+// by the window envelope of the same frames.  No integer division in any per-element loop (a thread keeps its frame /
+// walks its samples incrementally); the Hann window comes from the twiddle table.  79,872 B of LDS and <= 128 VGPRs: two
+// blocks per CU, so one block's loads overlap the other's transform.
+// (Measured alternatives, 240 s stereo: one block per CU with per-element divisions 0.29 ms; persistent blocks with register
+// prefetch of the next group, 239 VGPRs, one block per CU 0.165 ms.)
+template <int PMODE>                                        // phase_mode as a template argument: only its registers exist
+__global__ __launch_bounds__(512, 2) void istft_kernel(IstftArgs p, int ngroups) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int BUF = FftSize<NFFT>::BUF, TW = FftSize<NFFT>::TW, NW = 8, NF = 2 * NW;
-  constexpr int NIT = (NBIN * NF + 511) / 512;              // staged values per thread and group (17: 513 * 16 / 512)
+  constexpr int NIT = (NBIN * NF + 511) / 512;              // staged values per thread (17: 513 * 16 / 512)
   float2* const fbuf = (float2*)smem;                       // [8][BUF]
   float2* const tw = fbuf + NW * BUF;
-  float* const win = (float*)(tw + TW);                     // [NFFT]
   float* const raw = (float*)fbuf;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int total = ngroups * p.channels;
-  fft_build_twiddles<NFFT>(tw, tid, 512);
-  for (int m = tid; m < NFFT; m += 512) win[m] = hann_at(m);
+  const int g = blockIdx.x, c = g / ngroups, t0 = (g - c * ngroups) * IGROUP;
   float2* const buf = fbuf + wave * BUF;
-  const float2* const ph = (const float2*)p.phase;
-
-  float sm[NIT], sa[PMODE == 3 ? NIT : 1];                  // staged magnitudes (x mask) / angles of the next group
-  float2 pa[PMODE == 1 ? 9 : 1], pb[PMODE == 1 ? 9 : 1];    // phasors of this wave's two frames of the next group (mode 1)
-  // 32-bit byte offsets into buffer descriptors (one VGPR per address in flight instead of two; the host checks that the
-  // views stay below 2 GiB); an out-of-range element is pointed past num_records and reads as zero
+  // 32-bit byte offsets into buffer descriptors (one VGPR per address in flight; the host checks that the views stay below
+  // 2 GiB); an out-of-range element is pointed past num_records and reads as zero
   constexpr unsigned OOB = 0x80000000u;
   const __amdgpu_buffer_rsrc_t rmag = __builtin_amdgcn_make_buffer_rsrc((void*)p.mag, 0, OOB, 0x00020000);
   const __amdgpu_buffer_rsrc_t rmask = __builtin_amdgcn_make_buffer_rsrc((void*)(p.mask ? p.mask : p.mag), 0, OOB, 0x00020000);
   const __amdgpu_buffer_rsrc_t rph = __builtin_amdgcn_make_buffer_rsrc((void*)p.phase, 0, OOB, 0x00020000);
   const bool has_mask = p.mask != nullptr;
-  auto fetch = [&](int g) {
-    const int c = g / ngroups, t0 = (g - c * ngroups) * IGROUP;
+  // ---- loads first (in flight while the twiddles are built): this thread's frame column, and this wave's phasors
+  float sm[NIT], sa[PMODE == 3 ? NIT : 1];
+  {
+    const int tf = t0 - 1 + (tid & (NF - 1));               // a thread keeps its frame: one tile division per thread
+    const bool tok = tf >= 0 && tf < p.T;
+    const unsigned cbase = tok ? (unsigned)p.lay.col(c, tf) : 0u;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      const int e = tid + 512 * it;
-      const int k = e / NF, f = e - k * NF, t = t0 - 1 + f;
-      const bool ok = e < NBIN * NF && k >= p.lay.first_bin && t >= 0 && t < p.T;
-      const unsigned off = ok ? (unsigned)p.lay.at(c, k, t) * 4u : OOB;
+      const int k = (tid >> 4) + (512 / NF) * it;
+      const bool ok = tok && k < NBIN && k >= p.lay.first_bin;
+      const unsigned off = ok ? (cbase + (unsigned)(k * p.lay.seg)) * 4u : OOB;
       float m = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rmag, (int)off, 0, 0));
       if (has_mask) {
         const float mk = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rmask, (int)off, 0, 0));
@@ -263,115 +288,103 @@ __global__ __launch_bounds__(512) void istft_kernel(IstftArgs p, int ngroups) {
       sm[it] = m;
       if (PMODE == 3) sa[PMODE == 3 ? it : 0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rph, (int)off, 0, 0));
     }
-    if (PMODE == 1) {
-      const int ta = t0 - 1 + 2 * wave;
-      struct F2 { float x, y; };                          // (bit_cast: whatever 8-byte type the builtin returns)
+  }
+  float2 pa[PMODE == 1 ? 9 : 1], pb[PMODE == 1 ? 9 : 1];
+  const int ta = t0 - 1 + 2 * wave;
+  if (PMODE == 1) {
+    struct F2 { float x, y; };                              // (bit_cast: whatever 8-byte type the builtin returns)
 #pragma unroll
-      for (int r = 0; r < 9; ++r) {
-        const int k = lane + 64 * r;
-        const bool oka = k <= NFFT / 2 && ta >= 0 && ta < p.T, okb = k <= NFFT / 2 && ta + 1 >= 0 && ta + 1 < p.T;
-        const unsigned oa = oka ? (unsigned)(((long)c * p.T + ta) * NBIN + k) * 8u : OOB;
-        const unsigned ob = okb ? (unsigned)(((long)c * p.T + ta + 1) * NBIN + k) * 8u : OOB;
-        const F2 va = __builtin_bit_cast(F2, __builtin_amdgcn_raw_buffer_load_b64(rph, (int)oa, 0, 0));
-        const F2 vb = __builtin_bit_cast(F2, __builtin_amdgcn_raw_buffer_load_b64(rph, (int)ob, 0, 0));
-        pa[PMODE == 1 ? r : 0] = float2{va.x, va.y};
-        pb[PMODE == 1 ? r : 0] = float2{vb.x, vb.y};
-      }
+    for (int r = 0; r < 9; ++r) {
+      const int k = lane + 64 * r;
+      const bool oka = k <= NFFT / 2 && ta >= 0 && ta < p.T, okb = k <= NFFT / 2 && ta + 1 >= 0 && ta + 1 < p.T;
+      const unsigned oa = oka ? (unsigned)(((long)c * p.T + ta) * NBIN + k) * 8u : OOB;
+      const unsigned ob = okb ? (unsigned)(((long)c * p.T + ta + 1) * NBIN + k) * 8u : OOB;
+      const F2 va = __builtin_bit_cast(F2, __builtin_amdgcn_raw_buffer_load_b64(rph, (int)oa, 0, 0));
+      const F2 vb = __builtin_bit_cast(F2, __builtin_amdgcn_raw_buffer_load_b64(rph, (int)ob, 0, 0));
+      pa[PMODE == 1 ? r : 0] = float2{va.x, va.y};
+      pb[PMODE == 1 ? r : 0] = float2{vb.x, vb.y};
     }
-  };
-  int g = blockIdx.x;
-  if (g < total) fetch(g);
+  }
+  fft_build_twiddles<NFFT>(tw, tid, 512);
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int k = (tid >> 4) + (512 / NF) * it, f = tid & (NF - 1);
+    if (k < NBIN) {
+      const int w = f >> 1, at = 2 * (w * BUF + k + w) + (f & 1);
+      raw[at] = sm[it];
+      if (PMODE == 3) raw[at + BUF] = sa[PMODE == 3 ? it : 0];       // BUF floats = half a buffer higher
+    }
+  }
+  __syncthreads();
+  // spectra of this wave's two frames into registers (imaginary parts of DC / Nyquist dropped, as irfft does)
+  float2 Sa[9], Sb[9];
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    const int k = lane + 64 * r;
+    Sa[r] = Sb[r] = float2{0.f, 0.f};
+    if (k > NFFT / 2) continue;
+    const float2 m = buf[k + wave];
+    float2 qa = pa[PMODE == 1 ? r : 0], qb = pb[PMODE == 1 ? r : 0];
+    if (PMODE == 3) {
+      const float2 a = buf[k + wave + BUF / 2];
+      sincosf(a.x, &qa.y, &qa.x);
+      sincosf(a.y, &qb.y, &qb.x);
+    }
+    const bool edge = (k == 0 || k == NFFT / 2);
+    Sa[r] = float2{m.x * qa.x, edge ? 0.f : m.x * qa.y};
+    Sb[r] = float2{m.y * qb.x, edge ? 0.f : m.y * qb.y};
+  }
+  // conj(Z) with Z = Sa + i Sb (Hermitian-extended): the forward transform of conj(Z) is conj(ifft(Z)) = a - i b
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    const int k = lane + 64 * r;
+    if (k > NFFT / 2) continue;
+    buf[fft_pad(k)] = float2{Sa[r].x - Sb[r].y, -(Sa[r].y + Sb[r].x)};
+    if (k > 0 && k < NFFT / 2) buf[fft_pad(NFFT - k)] = float2{Sa[r].x + Sb[r].y, -(Sb[r].x - Sa[r].y)};
+  }
+  fft_wave<NFFT>(buf, tw, lane);
+  __syncthreads();
+  // ---- output: sample rel = hop * (f - 1) + m of local frame f; at most frames f_hi (m < hop) and f_hi - 1 (m + hop < n_fft)
+  const int span = IGROUP * p.hop;
   float vmax = 0.f;
-  int c_cur = g < total ? g / ngroups : 0;
-  // per-channel |y| maxima: partial[c][block]; a block's groups come channel by channel, so it flushes on a channel change
-  auto flush_max = [&](int c) {
+  {
+    int fh = tid / p.hop + 1, m = tid - (fh - 1) * p.hop;   // sample e = tid: local frame fh (m < hop); advanced without divisions
+    float* const yc = p.y + (long)c * p.n_out + ((long)p.hop * t0 - NFFT / 2);
+    const long ilo = NFFT / 2 - (long)p.hop * t0, ihi = p.n_out + ilo;       // valid e: ilo <= e < ihi
+    for (int e = tid; e < span; e += 512) {
+      if (e >= ilo && e < ihi) {
+        const int th = t0 - 1 + fh;                         // global index of frame fh; fh - 1 is th - 1
+        const float w1 = hann_fast(m);
+        const float2 z1 = fbuf[(fh >> 1) * BUF + fft_pad(m)];
+        float s = ((fh & 1) ? -z1.y : z1.x) * w1;           // (frames outside [0, T) hold zeros)
+        float env = (th >= 0 && th < p.T) ? w1 * w1 : 0.f;  // window envelope over the same (at most two) frames
+        if (m + p.hop < NFFT) {
+          const float w0 = hann_fast(m + p.hop);
+          const float2 z0 = fbuf[((fh - 1) >> 1) * BUF + fft_pad(m + p.hop)];
+          s += (((fh - 1) & 1) ? -z0.y : z0.x) * w0;
+          if (th - 1 >= 0 && th - 1 < p.T) env += w0 * w0;
+        }
+        s *= 1.0f / NFFT;
+        const float v = env > 1.1754944e-38f ? s * __builtin_amdgcn_rcpf(env) : s;
+        yc[e] = v;
+        vmax = fmaxf(vmax, fabsf(v));
+      }
+      m += 512;
+      while (m >= p.hop) { m -= p.hop; ++fh; }
+    }
+  }
+  if (p.absmax_partial) {                                   // partial[c][group]: max |y| of this block
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
     __syncthreads();
-    if (lane == 0) win[wave] = vmax;                        // (the window table is rebuilt below)
+    if (lane == 0) raw[wave] = vmax;
     __syncthreads();
     if (tid == 0) {
-      float m = win[0];
-      for (int w = 1; w < NW; ++w) m = fmaxf(m, win[w]);
-      p.absmax_partial[(long)c * gridDim.x + blockIdx.x] = m;
-    }
-    __syncthreads();
-    for (int m = tid; m < NW; m += 512) win[m] = hann_at(m);
-    vmax = 0.f;
-  };
-  if (p.absmax_partial)
-    for (int c = tid; c < p.channels; c += 512) p.absmax_partial[(long)c * gridDim.x + blockIdx.x] = 0.f;
-  for (; g < total; g += gridDim.x) {
-    const int c = g / ngroups, t0 = (g - c * ngroups) * IGROUP;
-    if (p.absmax_partial && c != c_cur) { flush_max(c_cur); c_cur = c; }
-    __syncthreads();                                        // the previous group's output threads are done with the buffers (first pass: tables built)
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int e = tid + 512 * it;
-      if (e < NBIN * NF) {
-        const int k = e / NF, f = e - k * NF, w = f >> 1, at = 2 * (w * BUF + k + w) + (f & 1);
-        raw[at] = sm[it];
-        if (PMODE == 3) raw[at + BUF] = sa[PMODE == 3 ? it : 0];      // BUF floats = half a buffer higher
-      }
-    }
-    __syncthreads();
-    // spectra of this wave's two frames into registers (imaginary parts of DC / Nyquist dropped, as irfft does)
-    float2 Sa[9], Sb[9];
-#pragma unroll
-    for (int r = 0; r < 9; ++r) {
-      const int k = lane + 64 * r;
-      Sa[r] = Sb[r] = float2{0.f, 0.f};
-      if (k > NFFT / 2) continue;
-      const float2 m = buf[k + wave];
-      float2 qa = pa[PMODE == 1 ? r : 0], qb = pb[PMODE == 1 ? r : 0];
-      if (PMODE == 3) {
-        const float2 a = buf[k + wave + BUF / 2];
-        sincosf(a.x, &qa.y, &qa.x);
-        sincosf(a.y, &qb.y, &qb.x);
-      }
-      const bool edge = (k == 0 || k == NFFT / 2);
-      Sa[r] = float2{m.x * qa.x, edge ? 0.f : m.x * qa.y};
-      Sb[r] = float2{m.y * qb.x, edge ? 0.f : m.y * qb.y};
-    }
-    // conj(Z) with Z = Sa + i Sb (Hermitian-extended): the forward transform of conj(Z) is conj(ifft(Z)) = a - i b
-#pragma unroll
-    for (int r = 0; r < 9; ++r) {
-      const int k = lane + 64 * r;
-      if (k > NFFT / 2) continue;
-      buf[fft_pad(k)] = float2{Sa[r].x - Sb[r].y, -(Sa[r].y + Sb[r].x)};
-      if (k > 0 && k < NFFT / 2) buf[fft_pad(NFFT - k)] = float2{Sa[r].x + Sb[r].y, -(Sb[r].x - Sa[r].y)};
-    }
-    fft_wave<NFFT>(buf, tw, lane);
-    if (g + (int)gridDim.x < total) fetch(g + gridDim.x);   // next group's inputs: in flight during the output pass (issued here,
-                                                            // after the transform, so that its registers are free)
-    __syncthreads();
-    // ---- output: sample rel = hop * (f - 1) + m of local frame f; at most frames f_hi (m < hop) and f_hi - 1 (m + hop < n_fft)
-    const int span = IGROUP * p.hop;
-    for (int e = tid; e < span; e += 512) {
-      const long q = (long)p.hop * t0 + e;                  // padded position
-      const long i = q - NFFT / 2;
-      if (i < 0 || i >= p.n_out) continue;
-      const int fh = e / p.hop + 1, m = e - (fh - 1) * p.hop;
-      const float2 z1 = fbuf[(fh >> 1) * BUF + fft_pad(m)];
-      float s = ((fh & 1) ? -z1.y : z1.x) * win[m];         // (frames outside [0, T) hold zeros)
-      if (m + p.hop < NFFT) {
-        const float2 z0 = fbuf[((fh - 1) >> 1) * BUF + fft_pad(m + p.hop)];
-        s += (((fh - 1) & 1) ? -z0.y : z0.x) * win[m + p.hop];
-      }
-      s *= 1.0f / NFFT;
-      // window envelope: the frames t with hop t <= q < hop t + n_fft, 0 <= t < T (same rule as the frames above, global t)
-      long t1 = q / p.hop;
-      if (t1 > p.T - 1) t1 = p.T - 1;
-      long tl = q - (NFFT - 1);
-      tl = tl <= 0 ? 0 : (tl + p.hop - 1) / p.hop;
-      float env = 0.f;
-      for (long t = tl; t <= t1; ++t) { const float w = win[q - t * p.hop]; env += w * w; }
-      const float v = env > 1.1754944e-38f ? s / env : s;
-      p.y[(long)c * p.n_out + i] = v;
-      vmax = fmaxf(vmax, fabsf(v));
+      float m = raw[0];
+      for (int w = 1; w < NW; ++w) m = fmaxf(m, raw[w]);
+      p.absmax_partial[g] = m;
     }
   }
-  if (p.absmax_partial && blockIdx.x < total) flush_max(c_cur);
 }
 
 // (R, C) float2 matrix -> (C, R): f-major phasors of a .npy file <-> the frame-major form the kernels stream
@@ -395,8 +408,7 @@ __global__ __launch_bounds__(256) void transpose_c64_kernel(const float2* __rest
 static size_t fwd_lds_bytes(bool dmag) {       // 79,872 B: two blocks per CU
   return (size_t)8 * FftSize<NFFT>::BUF * 8 + FftSize<NFFT>::TW * 8 + (dmag ? NBIN * SROW * 4 : 0);
 }
-static size_t inv_lds_bytes() { return (size_t)8 * FftSize<NFFT>::BUF * 8 + FftSize<NFFT>::TW * 8 + NFFT * 4; }
-#define ISTFT_MAX_BLOCKS 256      // persistent: one block (8 waves, 84 KB of LDS) per CU
+static size_t inv_lds_bytes() { return (size_t)8 * FftSize<NFFT>::BUF * 8 + FftSize<NFFT>::TW * 8; }    // 79,872 B: two blocks per CU
 template <class K>
 static int allow_lds(K kernel, size_t bytes) {
   SVS_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
@@ -440,11 +452,8 @@ extern "C" int svs_stft_fwd(const float* y, int64_t n_samples, int n_fft, int ho
 
 // padded length n_fft + hop * (T - 1): the last samples belong to group floor((padded - 1) / (15 hop))
 static int svs_istft_groups_per_channel(int hop, int frames) { return (int)((NFFT + (long)hop * (frames - 1) + (long)IGROUP * hop - 1) / ((long)IGROUP * hop)); }
-// persistent blocks of svs_istft_tiles = absmax partials per channel (layout [channel][block])
-extern "C" int svs_istft_groups(int hop, int frames, int channels) {
-  const long total = (long)svs_istft_groups_per_channel(hop, frames) * channels;
-  return (int)(total < ISTFT_MAX_BLOCKS ? total : ISTFT_MAX_BLOCKS);
-}
+// blocks per channel of svs_istft_tiles = absmax partials per channel (layout [channel][group])
+extern "C" int svs_istft_groups(int hop, int frames, int channels) { (void)channels; return svs_istft_groups_per_channel(hop, frames); }
 
 extern "C" int svs_istft_tiles(const float* mag, int64_t chan_stride, int seg, int rows, int first_bin, const float* mask, int invert,
                                const float* phase, int phase_mode, int channels, int n_fft, int hop, int frames, float* y,
@@ -466,7 +475,7 @@ extern "C" int svs_istft_tiles(const float* mag, int64_t chan_stride, int seg, i
   if ((rc = phase_mode == 1 ? allow_lds(istft_kernel<1>, lds) : allow_lds(istft_kernel<3>, lds))) return rc;
   const int ngroups = svs_istft_groups_per_channel(hop, frames);
   const long total = (long)ngroups * channels;
-  const dim3 grid((unsigned)(total < ISTFT_MAX_BLOCKS ? total : ISTFT_MAX_BLOCKS));
+  const dim3 grid((unsigned)total);
   if (phase_mode == 1) hipLaunchKernelGGL(istft_kernel<1>, grid, dim3(512), lds, stream, a, ngroups);
   else hipLaunchKernelGGL(istft_kernel<3>, grid, dim3(512), lds, stream, a, ngroups);
   SVS_CHECK_LAUNCH("istft");
