@@ -348,29 +348,27 @@ __global__ __launch_bounds__(512, 2) void istft_kernel(IstftArgs p, int ngroups)
   const int span = IGROUP * p.hop;
   float vmax = 0.f;
   {
-    int fh = tid / p.hop + 1, m = tid - (fh - 1) * p.hop;   // sample e = tid: local frame fh (m < hop); advanced without divisions
+    // A thread keeps its position m inside the hop and walks the 15 hops: the two window values (and, away from the ends of
+    // the signal, the envelope) are computed once per thread, and which frames exist is uniform across the block per hop.
     float* const yc = p.y + (long)c * p.n_out + ((long)p.hop * t0 - NFFT / 2);
     const long ilo = NFFT / 2 - (long)p.hop * t0, ihi = p.n_out + ilo;       // valid e: ilo <= e < ihi
-    for (int e = tid; e < span; e += 512) {
-      if (e >= ilo && e < ihi) {
-        const int th = t0 - 1 + fh;                         // global index of frame fh; fh - 1 is th - 1
-        const float w1 = hann_fast(m);
-        const float2 z1 = fbuf[(fh >> 1) * BUF + fft_pad(m)];
-        float s = ((fh & 1) ? -z1.y : z1.x) * w1;           // (frames outside [0, T) hold zeros)
-        float env = (th >= 0 && th < p.T) ? w1 * w1 : 0.f;  // window envelope over the same (at most two) frames
-        if (m + p.hop < NFFT) {
-          const float w0 = hann_fast(m + p.hop);
-          const float2 z0 = fbuf[((fh - 1) >> 1) * BUF + fft_pad(m + p.hop)];
-          s += (((fh - 1) & 1) ? -z0.y : z0.x) * w0;
-          if (th - 1 >= 0 && th - 1 < p.T) env += w0 * w0;
-        }
-        s *= 1.0f / NFFT;
+    for (int m = tid; m < p.hop; m += 512) {
+      const bool two = m + p.hop < NFFT;                    // frame fh - 1 still covers this position
+      const float w1 = hann_fast(m) * (1.0f / NFFT), w0 = two ? hann_fast(m + p.hop) * (1.0f / NFFT) : 0.f;
+      const float e1 = w1 * w1 * (float)(NFFT * NFFT), e0 = w0 * w0 * (float)(NFFT * NFFT);
+      const int a1 = fft_pad(m), a0 = fft_pad(two ? m + p.hop : 0);
+#pragma unroll 5
+      for (int fh = 1; fh <= IGROUP; ++fh) {
+        const int e = (fh - 1) * p.hop + m;
+        if (e < ilo || e >= ihi) continue;
+        const int th = t0 - 1 + fh;                         // global index of local frame fh; fh - 1 is th - 1
+        const float2 z1 = fbuf[(fh >> 1) * BUF + a1], z0 = fbuf[((fh - 1) >> 1) * BUF + a0];
+        const float s = ((fh & 1) ? -z1.y : z1.x) * w1 + ((fh & 1) ? z0.x : -z0.y) * w0;     // (frames outside [0, T) hold zeros)
+        const float env = ((th >= 0 && th < p.T) ? e1 : 0.f) + ((th - 1 >= 0 && th - 1 < p.T) ? e0 : 0.f);
         const float v = env > 1.1754944e-38f ? s * __builtin_amdgcn_rcpf(env) : s;
         yc[e] = v;
         vmax = fmaxf(vmax, fabsf(v));
       }
-      m += 512;
-      while (m >= p.hop) { m -= p.hop; ++fh; }
     }
   }
   if (p.absmax_partial) {                                   // partial[c][group]: max |y| of this block
