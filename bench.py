@@ -130,47 +130,153 @@ def time_gemm_calls(B, mode, reps=10, only_kernel=None):
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the rocprofv3 --pmc passes kept under profiles/ (FETCH_SIZE doubled per
-    the gfx950 correction of MI355X_MICROARCH.md, WRITE_SIZE as is); None when no summary covers the kernel."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            return json.load(f).get(kernel, {}).get("hbm_bytes_per_launch")
-    except Exception:
-        return None
+    """(HBM bytes per launch of `kernel`, source) from the newest rocprofv3 --pmc summary kept under profiles/ (two separate
+    passes, FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md, WRITE_SIZE as is -- tools/pmc_traffic.py).
+    The counters cannot be collected from inside a timed run, so this is a RECORDED number: `source` names the file (which
+    carries the commit it was taken at); (None, None) when no summary covers the kernel."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            if kernel in d:
+                return d[kernel].get("hbm_bytes_per_launch"), os.path.relpath(path, ROOT) + (" @ " + d["_commit"] if "_commit" in d else "")
+        except Exception:
+            pass
+    return None, None
 
 
-def cpu_baseline(mode, seconds_budget=20.0):
-    """The CPU oracle (oracle/unet_oracle.py) on this box's host cores: same synthetic tiles, fp32."""
-    from oracle import unet_oracle as uo
-    # the box gives one GPU's job a 16-CPU share, whatever os.cpu_count() says
-    cores = min(len(os.sched_getaffinity(0)), 16)
-    torch.set_num_threads(cores)
-    B = 16
-    mix_np, voc_np = synth.tiles(B)
-    mix, voc = torch.from_numpy(mix_np), torch.from_numpy(voc_np)
-    st = uo.to_torch_state(synth.closed_form_state(trained_stats=False))
-    if mode == "train":
-        opt = uo.new_adam_state(st)
-        masks = [torch.from_numpy(m) for m in synth.dropout_masks(B, seed=1)]
-        step = lambda: uo.train_step(st, opt, mix, voc, dropout_masks=masks, loss_scale=ALPHA_L1)
-    else:
-        def step():
-            with torch.no_grad():
-                uo.forward(st, mix, training=False)
-    for _ in range(2):
-        step()
-    t0 = time.perf_counter()
-    it = 0
-    while True:
-        step()
-        it += 1
-        el = time.perf_counter() - t0
-        if el > seconds_budget or it >= 40:
+def usable_cores():
+    """CPU threads this process can really run: the affinity mask, cut to the cgroup CPU quota when there is one (a GPU box
+    hands one GPU's job a 16-CPU share of a much larger host; oversubscribing it makes the oracle many times slower)."""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(float(parts[0]) / float(parts[1]) + 0.5)))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                        n = min(n, max(1, int(q / int(g.read()) + 0.5)))
             break
-    return {"value": round(B * it / el, 2), "unit": "tiles/s", "cores": cores, "kind": "port",
-            "sample": f"{it} {'L1 train steps (fwd+bwd+Adam)' if mode == 'train' else 'eval forwards'} of batch {B}, "
-                      f"fp32 torch CPU oracle, {cores} threads, {el:.1f} s"}
+        except (OSError, ValueError, IndexError):
+            continue
+    return min(n, 16)              # SURVEY 8(d): the share of one GPU's job on the pool's hosts
+
+
+def cpu_baseline(mode, seconds_budget=24.0):
+    """The CPU oracle (oracle/unet_oracle.py, the plain-torch restatement of the reference) on this box's host cores, fp32,
+    same synthetic tiles: the three cases of SURVEY.md 8(d) -- config 1 (eval forward B=1, the inference.py tile loop),
+    eval forward B=16, one L1 train step (fwd + bwd + Adam) at B=64 -- 2 warm-up + >= 5 timed iterations each within a
+    bounded budget.  `value` is the case that corresponds to the GPU line of this run."""
+    from oracle import unet_oracle as uo
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    cpu_model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "")
+    except OSError:
+        pass
+    st = uo.to_torch_state(synth.closed_form_state(trained_stats=False))
+
+    def run(B, train, budget):
+        mix_np, voc_np = synth.tiles(B)
+        mix, voc = torch.from_numpy(mix_np), torch.from_numpy(voc_np)
+        if train:
+            opt = uo.new_adam_state(st)
+            masks = [torch.from_numpy(m) for m in synth.dropout_masks(B, seed=1)]
+            step = lambda: uo.train_step(st, opt, mix, voc, dropout_masks=masks, loss_scale=ALPHA_L1)
+        else:
+            def step():
+                with torch.no_grad():
+                    uo.forward(st, mix, training=False)
+        for _ in range(2):
+            step()
+        t0 = time.perf_counter()
+        it = 0
+        while True:
+            step()
+            it += 1
+            el = time.perf_counter() - t0
+            if (it >= 5 and el > budget) or it >= 50:
+                break
+        return {"tiles_per_s": round(B * it / el, 2), "batch": B, "iterations": it, "seconds": round(el, 2)}
+
+    cases = {"eval_b1": run(1, False, seconds_budget / 8), "eval_b16": run(16, False, seconds_budget / 4),
+             "train_b64": run(64, True, seconds_budget / 2)}
+    key = "train_b64" if mode == "train" else "eval_b16"
+    return {"value": cases[key]["tiles_per_s"], "unit": "tiles/s", "cores": cores, "kind": "port", "cpu": cpu_model,
+            "sample": f"{cases[key]['iterations']} {'L1 train steps (fwd+bwd+Adam)' if mode == 'train' else 'eval forwards'} of batch "
+                      f"{cases[key]['batch']}, fp32 torch CPU oracle, {cores} threads, {cases[key]['seconds']} s",
+            "cases": cases}
+
+
+def eval_record(model, dev, B=16, steps=30, warmup=5):
+    """BASELINE configs[1]: eval forward at B = 16, eager and replayed from a hipGraph (the forward is one graph of 12
+    launches; the replay removes the host launch cost that an eager B=16 forward is bound by)."""
+    H, W = 512, 128
+    mix = torch.empty((B, 1, H, W), device=dev)
+    voc = torch.empty_like(mix)
+    _lib.check(_lib.lib().svs_fill_tiles(mix.data_ptr(), voc.data_ptr(), B, H, W, 10_000, _lib.stream_ptr()), "svs_fill_tiles")
+    was = model.training
+    model.eval()
+    out = {}
+    with torch.no_grad():
+        for _ in range(warmup):
+            model(mix)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            model(mix)
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / steps
+        out["eager"] = {"ms": round(ms, 4), "tiles_per_s": round(B / ms * 1e3, 1),
+                        "frac": round(B / ms * 1e3 * FWD_GFLOP_PER_TILE / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4)}
+        try:
+            replay = model.graphed_forward(mix)
+            for _ in range(warmup):
+                replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                replay()
+            torch.cuda.synchronize()
+            ms = 1e3 * (time.perf_counter() - t0) / steps
+            out["graph"] = {"ms": round(ms, 4), "tiles_per_s": round(B / ms * 1e3, 1),
+                            "frac": round(B / ms * 1e3 * FWD_GFLOP_PER_TILE / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4)}
+        except Exception as e:                      # the graph path is an optimisation, never a correctness dependency
+            out["graph_error"] = str(e)[:200]
+    model.train(was)
+    out["batch"] = B
+    out["roofline_tiles_per_s"] = round(FP32_MFMA_PEAK_TFLOPS * 1e3 / FWD_GFLOP_PER_TILE, 1)
+    return out
+
+
+def strong_record(model, dev, world, rank, grad_sync, global_batch=512, steps=6, warmup=2):
+    """Train step at a FIXED global batch of 512 tiles split over the ranks (north_star's strong-scaling target is quoted on
+    this): per-GPU batch 512 / world.  Rank-local timing (the caller reduces with MAX over ranks when world > 1)."""
+    B = global_batch // world
+    H, W = 512, 128
+    mix = torch.empty((B, 1, H, W), device=dev)
+    voc = torch.empty_like(mix)
+    _lib.check(_lib.lib().svs_fill_tiles(mix.data_ptr(), voc.data_ptr(), B, H, W, 20_000 + rank * B, _lib.stream_ptr()), "svs_fill_tiles")
+    model.train()
+    for _ in range(warmup):
+        model.train_step(mix, voc, loss_scale=ALPHA_L1, grad_sync=grad_sync)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        model.train_step(mix, voc, loss_scale=ALPHA_L1, grad_sync=grad_sync)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    model._ws.clear()                                   # the B=512 workspace is 9.7 GB: give it back
+    return {"global_batch": global_batch, "per_gpu_batch": B, "n_gpus": world, "ms_per_step": round(1e3 * el / steps, 4),
+            "tiles_per_s": round(global_batch * steps / el, 1), "scaling": "strong"}
 
 
 def main():
@@ -182,6 +288,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="tiles per GPU (default 64 train / 16 eval)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-layers", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the eval-B16 / strong-scaling / signal-kernel sub-records")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even with one rank")
     args = ap.parse_args()
 
@@ -245,6 +352,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # strong-scaling point of north_star (outside the timed region above): global batch 512 split over the ranks, every rank
+    # takes part, MAX over ranks
+    strong = None
+    if args.mode == "train" and not args.no_extras:
+        fence()
+        strong = strong_record(model, dev, world, rank, grad_sync)
+        if dist is not None:
+            t = torch.tensor([strong["ms_per_step"]], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            strong["ms_per_step"] = round(float(t.item()), 4)
+            strong["tiles_per_s"] = round(strong["global_batch"] / strong["ms_per_step"] * 1e3, 1)
+
     if rank == 0:
         tiles_per_s = world * B * args.steps / elapsed
         gflop = TRAIN_GFLOP_PER_TILE if args.mode == "train" else FWD_GFLOP_PER_TILE
@@ -258,6 +377,8 @@ def main():
                        "global_batch": B * world, "parallelism": f"dp{world}", "mode": args.mode},
             "conv_roofline_frac": round(tiles_per_s / world * gflop / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4),
         }
+        if strong is not None:
+            res["strong_b512"] = strong
         if world == 1:
             if not args.no_layers:
                 calls = time_gemm_calls(B, args.mode)
@@ -276,7 +397,7 @@ def main():
                 gf_in_image = sum(c[4] * c[5] for c in alone)
                 ach = gf / ms            # GFLOP / ms = TFLOP/s
                 res["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                                   "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(dom),
+                                   "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(dom)[0], "traffic_source": pmc_traffic(dom)[1],
                                    "launches_per_step": cnt, "avg_launch_ms": round(ms / cnt, 4),
                                    "algorithmic_gflop_per_launch": round(gf / cnt, 3),
                                    "achieved_in_image": round(gf_in_image / ms, 2),
@@ -288,6 +409,15 @@ def main():
                 res["kernels"] = {k: {"calls": v[2], "ms": round(v[0], 4), "tflops": round(v[1] / v[0], 2)} for k, v in fam.items()}
                 res["layers"] = {name: {"kernel": kernel, "ksplit": ks, "ms": round(ms, 4), "tflops": round(gf / ms, 2),
                                         "in_image": round(fr, 3)} for name, kernel, ks, ms, gf, fr in calls}
+            if not args.no_extras:
+                if args.mode == "train":
+                    res["eval_b16"] = eval_record(model, dev)                  # BASELINE configs[1]
+                try:
+                    sys.path.insert(0, os.path.join(ROOT, "tools"))
+                    from signal_bench import signal_record
+                    res["signal"] = signal_record(240.0, 44100, 64)            # STFT / iSTFT GB/s, MR-STFT loss ms (configs[4] pieces)
+                except Exception as e:
+                    res["signal_error"] = str(e)[:200]
             if not args.no_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline(args.mode)
         print(json.dumps(res), flush=True)

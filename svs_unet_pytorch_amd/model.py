@@ -352,8 +352,7 @@ class UNet(nn.Module):
         # everything that can change the folded weights: in-place edits of any parameter / BatchNorm buffer (each
         # parameter has its own version counter: p.data is re-pointed at the flat buffer), and `_param_epoch`, which
         # every path that updates them through raw pointers bumps (training forwards, Adam, broadcasts, re-flattening)
-        key = (self._flat._version, self._bn_flat._version, self._param_epoch,
-               sum(p._version for p in self._param_list), sum(b._version for b in self._bn_views()))
+        key = self._eval_key()
         if self._prepared is None or self._prepared_key != key:
             if self._prepared is None:
                 self._prepared = torch.empty(int(lib().svs_unet_prepared_bytes()), dtype=torch.uint8, device=self._flat.device)
@@ -365,6 +364,13 @@ class UNet(nn.Module):
         check(lib().svs_unet_forward_eval(ptr(self._prepared), ptr(mix), ptr(mask), B, H, W, ptr(ws), ws.numel(),
                                           _lib.stream_ptr()), "svs_unet_forward_eval")
         return mask
+
+    def _eval_key(self):
+        """Everything that can change the folded eval weights: in-place edits of any parameter / BatchNorm buffer (each
+        parameter has its own version counter: p.data is re-pointed at the flat buffer), and `_param_epoch`, which every
+        path that updates them through raw pointers bumps (training forwards, Adam, broadcasts, re-flattening)."""
+        return (self._flat._version, self._bn_flat._version, self._param_epoch,
+                sum(p._version for p in self._param_list), sum(b._version for b in self._bn_views()))
 
     def _bn_views(self):
         for bn in self._bn_list:
@@ -402,6 +408,35 @@ class UNet(nn.Module):
         if tmp is not None:
             self._gflat.add_(tmp)
         self._grads_clean = False
+
+    @_on_model_device
+    def graphed_forward(self, static_mix):
+        """Captures the eval forward on `static_mix` (its storage is the graph's input: refill it in place) into a hipGraph
+        and returns `replay() -> mask`, whose result lives in a static output tensor.  Every launch of the library goes to
+        the caller's stream and nothing synchronises or allocates, so the 12 launches of a forward become one graph launch
+        (an eager forward at small batch is bound by host launch cost, not by the GPU)."""
+        assert not self.training, "graphed_forward is an inference path: call .eval() first"
+        static_mix = self._check_input(static_mix)
+        with torch.no_grad():
+            self._eval_forward(static_mix)                         # prepared weights + workspace exist before the capture
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream(device=static_mix.device)
+        side.wait_stream(torch.cuda.current_stream(static_mix.device))
+        with torch.cuda.stream(side), torch.no_grad():
+            self._eval_forward(static_mix)
+            side.synchronize()
+            with torch.cuda.graph(graph, stream=side):
+                static_out = self._eval_forward(static_mix)
+        torch.cuda.current_stream(static_mix.device).wait_stream(side)
+        key = self._prepared_key
+
+        def replay():
+            if self._prepared_key != key or self._eval_key() != key:
+                raise RuntimeError("UNet weights changed since the graph was captured: capture again")
+            graph.replay()
+            return static_out
+        replay.graph, replay.output, replay.input = graph, static_out, static_mix
+        return replay
 
     @_on_model_device
     def forward(self, mix):
