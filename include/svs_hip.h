@@ -250,6 +250,16 @@ int svs_unet_train_fwd_loss_mr(const float* params, float* bn_buffers, int64_t* 
                                void* mr_ws, size_t mr_ws_bytes, hipStream_t stream);
 int64_t svs_unet_ws_offset(const char* name, int B, int H, int W, int training);  /* bytes, <0 unknown */
 
+/* bf16 eval forward (BASELINE configs[4]: "bf16 convs on MFMA"): the same network with bf16 NHWC activations and bf16
+ * weights on v_mfma_f32_16x16x32_bf16, fp32 accumulation, BatchNorm folded, mix and mask still fp32.  Not bit-comparable with
+ * the fp32 path (activations are rounded to 8 significant bits per layer); tests report its mask L1 against the fp32 forward.
+ * prepared_f32 is the blob of svs_unet_prepare_eval. */
+size_t svs_unet_prepared_bf16_bytes(void);
+int svs_unet_prepare_eval_bf16(const void* prepared_f32, void* prepared_bf16, hipStream_t stream);
+size_t svs_unet_eval_bf16_workspace_bytes(int B, int H, int W);
+int svs_unet_forward_eval_bf16(const void* prepared_bf16, const float* mix, float* mask, int B, int H, int W, void* ws,
+                               size_t ws_bytes, hipStream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Signal front/back end (replaces librosa.stft / magphase / istft at data.py:79-80,100-101,159 and
  * torch.istft at train.py:51-58).  n_fft-point periodic-Hann STFT, centred with zero padding,

@@ -65,6 +65,10 @@ _SIGS = {
     "svs_unet_prepare_eval": (I, [P, P, P, P]),
     "svs_unet_eval_workspace_bytes": (Z, [I, I, I]),
     "svs_unet_forward_eval": (I, [P, P, P, I, I, I, P, Z, P]),
+    "svs_unet_prepared_bf16_bytes": (Z, []),
+    "svs_unet_prepare_eval_bf16": (I, [P, P, P]),
+    "svs_unet_eval_bf16_workspace_bytes": (Z, [I, I, I]),
+    "svs_unet_forward_eval_bf16": (I, [P, P, P, I, I, I, P, Z, P]),
     "svs_unet_train_workspace_bytes": (Z, [I, I, I]),
     "svs_unet_train_fwd_bwd": (I, [P, P, P, P, P, P, P, I, I, I, F, P, P, P, Z, P]),
     "svs_unet_train_forward": (I, [P, P, P, P, P, I, I, I, P, P, Z, P]),

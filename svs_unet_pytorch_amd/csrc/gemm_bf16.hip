@@ -1,0 +1,478 @@
+// bf16 eval forward of the U-Net on the bf16 MFMA (v_mfma_f32_16x16x32_bf16, fp32 accumulate), gfx950 -- BASELINE.json
+// configs[4] ("bf16 convs on MFMA"); the fp32 path (gemm_conv.hip) stays the parity reference.
+//
+// Same implicit GEMM as gemm_conv.hip (GATHER = Conv2d forward, PARITY = the four stride-1 sub-convolutions of a
+// ConvTranspose2d forward; reference model.py:47-109), with the operand layout chosen for the bf16 instruction:
+//   * activations are bf16 NHWC; a K-tile is 32 consecutive input channels of one tap = ONE 64-byte run per pixel, the same
+//     run a 16-channel fp32 K-tile is, so staging (16-byte buffer loads, XOR-swizzled 64-byte LDS rows, double buffering,
+//     one barrier per K-tile) is identical;
+//   * the 16-byte chunk a lane reads back with ds_read_b128 holds k = 8q .. 8q+7 of its row (q = lane >> 4): exactly the
+//     operand map of the 16x16x32 instruction (lane l: row l & 15, k = 8 (l >> 4) + j), so one fragment read feeds one MFMA
+//     that covers the whole K-tile (the fp32 form needs four 16x16x4 MFMAs per fragment);
+//   * eval-mode BatchNorm is folded: the per-channel scale goes into the bf16 weights, the shift and LeakyReLU / ReLU into
+//     the epilogue, which rounds to bf16 once (v_cvt_pk_bf16_f32) and stores 32-byte runs.
+// Level 1 is interleaved here ([decoder 16 | skip 16] = one 64-byte line per pixel): conv2 reads all 32 channels with zero
+// weights on the decoder half (which is therefore zero-filled at the start of a forward), so that no layer needs a 16-wide
+// K-tile.  Bound: HBM / launch at streaming batch sizes (bf16 MFMA peak ~2.5 PFLOP/s: 16x the fp32 rate).
+#include "internal.h"
+
+typedef unsigned short u16;
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ u16 to_bf16(float v) { return __builtin_bit_cast(u16, (__bf16)v); }
+__device__ __forceinline__ float from_bf16(u16 v) { return __builtin_bit_cast(float, (unsigned)v << 16); }
+
+struct ConvBf16Args {
+  const u16* x; long ldx;          // bf16 NHWC view, ld in elements
+  int B, H, W, C;                  // C % 32 == 0
+  const u16* wp;                   // packed bf16 weights, BatchNorm scale folded in: gather [n][tap][c], parity [class][n][th][tw][c]
+  const float* shift;              // [N] fp32 (folded BatchNorm shift incl. conv bias)
+  float slope;                     // LeakyReLU slope (0 = ReLU)
+  u16* y; long ldy;
+  int Ho, Wo, N;
+  int ksplit; float* slab;         // fp32 partial sums [ksplit][B*Ho*Wo][N] when ksplit > 1
+};
+
+enum { BF_GATHER = 0, BF_PARITY = 1 };
+__device__ __forceinline__ int swz16(int row, int chunk) { return chunk ^ ((row >> 1) & 3); }
+
+template <int MODE, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_gemm_bf16_kernel(ConvBf16Args p) {
+  constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+  constexpr int RA = (BM + 63) / 64, RB = (BN + 63) / 64;
+  static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "tile");
+  __shared__ __attribute__((aligned(16))) float As[2][BM * 16];     // 64-byte rows (32 bf16)
+  __shared__ __attribute__((aligned(16))) float Bs[2][BN * 16];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave / WN, wn = wave % WN, lrow = lane & 15, q = lane >> 4;
+  int ph = 0, pw = 0, nth = 5, ntw = 5, Ha, Wa;
+  const u16* wp = p.wp;
+  if (MODE == BF_PARITY) {
+    const int par = blockIdx.z;
+    ph = par >> 1; pw = par & 1;
+    nth = 3 - ph; ntw = 3 - pw;
+    Ha = (p.Ho - ph + 1) >> 1; Wa = (p.Wo - pw + 1) >> 1;
+    const int poff = (par == 0) ? 0 : (par == 1) ? 9 : (par == 2) ? 15 : 21;
+    wp += (long)poff * p.N * p.C;
+  } else { Ha = p.Ho; Wa = p.Wo; }
+  const int ntaps = nth * ntw;
+  const long M = (long)p.B * Ha * Wa;
+  const int ntile_n = p.N / BN;
+  const long m0 = (long)(blockIdx.x / ntile_n) * BM;
+  const int n0 = (blockIdx.x % ntile_n) * BN;
+  if (m0 >= M) return;
+  const int cpt = p.C >> 5;                                   // K-tiles (32 channels) per tap
+  const int nkt = ntaps * cpt;
+  const int kt_begin = (int)((long)nkt * blockIdx.y / p.ksplit), kt_end = (int)((long)nkt * (blockIdx.y + 1) / p.ksplit);
+  const long Kw = (long)ntaps * p.C;
+  const int chunk = t & 3;
+  constexpr unsigned OOB = 0x80000000u;
+  unsigned a_voff[RA], a_mask[RA];
+#pragma unroll
+  for (int r = 0; r < RA; ++r) {
+    const int row = (t >> 2) + 64 * r;
+    const long m = m0 + row;
+    const bool ok = (row < BM) && (m < M);
+    const long mm = ok ? m : 0;
+    const int wq = (int)(mm % Wa);
+    const long tmp = mm / Wa;
+    const int hq = (int)(tmp % Ha);
+    const long b = tmp / Ha;
+    const int h0 = (MODE == BF_GATHER) ? 2 * hq : hq, w0 = (MODE == BF_GATHER) ? 2 * wq : wq;
+    a_voff[r] = ok ? (unsigned)((((b * p.H + h0) * p.W + w0) * p.ldx + chunk * 8) * 2) : OOB;
+    unsigned mask = 0;
+    for (int th = 0; th < nth; ++th)
+      for (int tw = 0; tw < ntw; ++tw) {
+        const int ih = (MODE == BF_GATHER) ? h0 - 2 + th : h0 + 1 - th, iw = (MODE == BF_GATHER) ? w0 - 2 + tw : w0 + 1 - tw;
+        if (ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) mask |= 1u << (th * ntw + tw);
+      }
+    a_mask[r] = mask;
+  }
+  unsigned b_voff[RB];
+#pragma unroll
+  for (int r = 0; r < RB; ++r) {
+    const int row = (t >> 2) + 64 * r;
+    b_voff[r] = (row < BN) ? (unsigned)(((long)(n0 + row) * Kw + chunk * 8) * 2) : OOB;
+  }
+  const long shift_px = (MODE == BF_GATHER) ? (2L * p.W + 2) * p.ldx : (1L * p.W + 1) * p.ldx;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x - shift_px), 0, OOB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wp, 0, OOB, 0x00020000);
+  f32x4 ra[RA], rb[RB];
+  auto load_tile = [&](int kt) {                              // tap outer, channel chunk inner
+    const int tap = kt / cpt, cc = kt - tap * cpt;
+    const int th = (ntw == 5) ? tap / 5 : (ntw == 3) ? tap / 3 : tap >> 1;
+    const int tw = tap - th * ntw;
+    const int pix = (MODE == BF_GATHER) ? th * p.W + tw : (2 - th) * p.W + (2 - tw);
+    const int soff_a = __builtin_amdgcn_readfirstlane((int)((pix * p.ldx + (cc << 5)) * 2));
+    const int soff_b = __builtin_amdgcn_readfirstlane((int)(((long)tap * p.C + (cc << 5)) * 2));
+#pragma unroll
+    for (int r = 0; r < RA; ++r) {
+      const unsigned vo = ((a_mask[r] >> tap) & 1u) ? a_voff[r] : OOB;
+      ra[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)vo, soff_a, 0));
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) rb[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (int)b_voff[r], soff_b, 0));
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int r = 0; r < RA; ++r) {
+      const int row = (t >> 2) + 64 * r;
+      if (BM % 64 == 0 || row < BM) *(f32x4*)(&As[buf][row * 16 + swz16(row, chunk) * 4]) = ra[r];
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const int row = (t >> 2) + 64 * r;
+      if (BN % 64 == 0 || row < BN) *(f32x4*)(&Bs[buf][row * 16 + swz16(row, chunk) * 4]) = rb[r];
+    }
+  };
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (kt_begin < kt_end) { load_tile(kt_begin); store_tile(0); }
+  __syncthreads();
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int buf = (kt - kt_begin) & 1;
+    const bool more = kt + 1 < kt_end;
+    if (more) load_tile(kt + 1);
+    bf16x8 fa[TM], fb[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int row = wm * (TM * 16) + i * 16 + lrow;
+      fa[i] = __builtin_bit_cast(bf16x8, *(const f32x4*)(&As[buf][row * 16 + swz16(row, q) * 4]));
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int row = wn * (TN * 16) + j * 16 + lrow;
+      fb[j] = __builtin_bit_cast(bf16x8, *(const f32x4*)(&Bs[buf][row * 16 + swz16(row, q) * 4]));
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    if (more) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+  // epilogue: C/D map col = lane & 15, row = 4 (lane >> 4) + reg
+  const bool split = p.ksplit > 1;
+  float* const slab = split ? p.slab + (long)blockIdx.y * ((long)p.B * p.Ho * p.Wo) * p.N : nullptr;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long m = m0 + wm * (TM * 16) + i * 16 + q * 4 + r;
+      if (m >= M) continue;
+      long opix;
+      if (MODE == BF_GATHER) opix = m;
+      else {
+        const int wq = (int)(m % Wa);
+        const long tmp = m / Wa;
+        const int hq = (int)(tmp % Ha);
+        const long b = tmp / Ha;
+        opix = (b * p.Ho + 2 * hq + ph) * p.Wo + 2 * wq + pw;
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (TN * 16) + j * 16 + lrow;
+        float v = acc[i][j][r];
+        if (split) { slab[opix * p.N + n] = v; continue; }
+        v += p.shift[n];
+        v = v > 0.f ? v : v * p.slope;
+        p.y[opix * p.ldy + n] = to_bf16(v);
+      }
+    }
+}
+
+// out[pix][n] = bf16(act(sum_z slab[z][pix][n] + shift[n]))
+__global__ __launch_bounds__(256) void splitk_epilogue_bf16_kernel(const float* __restrict__ slab, int ksplit, long P, int N,
+                                                                   const float* __restrict__ shift, float slope, u16* y, long ldy) {
+  const long total4 = P * N / 4, stride = P * N;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+    const long e = i * 4, pix = e / N;
+    const int n = (int)(e - pix * N);
+    f32x4 s = *(const f32x4*)(slab + e);
+    for (int z = 1; z < ksplit; ++z) s += *(const f32x4*)(slab + z * stride + e);
+    u16 o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { float v = s[k] + shift[n + k]; v = v > 0.f ? v : v * slope; o[k] = to_bf16(v); }
+    *(uint2*)(y + pix * ldy + n) = make_uint2((unsigned)o[0] | ((unsigned)o[1] << 16), (unsigned)o[2] | ((unsigned)o[3] << 16));
+  }
+}
+
+// conv1 (model.py:47-51): 1 -> 16 channels, fp32 input tile; writes the whole 32-channel level-1 pixel: zeros in the
+// decoder half [0, 16) (conv2 reads it against zero weights before deconv5 fills it), the activations in [16, 32)
+__global__ __launch_bounds__(256) void conv1_bf16_kernel(const float* __restrict__ x, int B, int H, int W, const float* __restrict__ w /*[16][25] scale folded*/,
+                                                         const float* __restrict__ shift, float slope, u16* __restrict__ y, long ldy, int Ho, int Wo) {
+  const long P = (long)B * Ho * Wo;
+  const long pix = (long)blockIdx.x * 256 + threadIdx.x;
+  if (pix >= P) return;
+  const int ow = (int)(pix % Wo);
+  const long tmp = pix / Wo;
+  const int oh = (int)(tmp % Ho);
+  const long b = tmp / Ho;
+  const float* img = x + b * H * W;
+  float xin[25];
+#pragma unroll
+  for (int kh = 0; kh < 5; ++kh)
+#pragma unroll
+    for (int kw = 0; kw < 5; ++kw) {
+      const int ih = 2 * oh - 2 + kh, iw = 2 * ow - 2 + kw;
+      xin[kh * 5 + kw] = ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) ? img[(long)ih * W + iw] : 0.f;
+    }
+  unsigned pk[8];
+#pragma unroll
+  for (int n = 0; n < 16; n += 2) {
+    float a0 = shift[n], a1 = shift[n + 1];
+#pragma unroll
+    for (int tap = 0; tap < 25; ++tap) { a0 += xin[tap] * w[n * 25 + tap]; a1 += xin[tap] * w[(n + 1) * 25 + tap]; }
+    a0 = a0 > 0.f ? a0 : a0 * slope;
+    a1 = a1 > 0.f ? a1 : a1 * slope;
+    pk[n >> 1] = (unsigned)to_bf16(a0) | ((unsigned)to_bf16(a1) << 16);
+  }
+  uint4* dst = (uint4*)(y + pix * ldy);
+  dst[0] = make_uint4(0u, 0u, 0u, 0u);
+  dst[1] = make_uint4(0u, 0u, 0u, 0u);
+  dst[2] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+  dst[3] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+}
+
+// deconv6 + sigmoid (model.py:109,198-200): 32 bf16 channels -> 1 fp32 channel, gather form (each output pixel sums its
+// <= 9 in-range taps); neighbouring threads share their input lines through L1
+__global__ __launch_bounds__(256) void deconv6_bf16_kernel(const u16* __restrict__ x, long ldx, int B, int H, int W, const float* __restrict__ w /*[32][25]*/,
+                                                           const float* __restrict__ bias, float* __restrict__ y, int Ho, int Wo) {
+  __shared__ float wl[25][32];                                // [tap][c]
+  for (int i = threadIdx.x; i < 800; i += 256) wl[i % 25][i / 25] = w[i];
+  __syncthreads();
+  const long P = (long)B * Ho * Wo;
+  const long pix = (long)blockIdx.x * 256 + threadIdx.x;
+  if (pix >= P) return;
+  const int ow = (int)(pix % Wo);
+  const long tmp = pix / Wo;
+  const int oh = (int)(tmp % Ho);
+  const long b = tmp / Ho;
+  float acc = bias[0];
+#pragma unroll
+  for (int dh = 0; dh < 3; ++dh) {
+    const int kh = (oh & 1) + 2 * dh;                         // taps with (oh + 2 - kh) even
+    const int ih = (oh + 2 - kh) >> 1;
+    if (kh > 4 || (unsigned)ih >= (unsigned)H) continue;
+#pragma unroll
+    for (int dw = 0; dw < 3; ++dw) {
+      const int kw = (ow & 1) + 2 * dw;
+      const int iw = (ow + 2 - kw) >> 1;
+      if (kw > 4 || (unsigned)iw >= (unsigned)W) continue;
+      const uint4* src = (const uint4*)(x + ((b * H + ih) * W + iw) * ldx);
+      const float* wt = wl[kh * 5 + kw];
+#pragma unroll
+      for (int v4 = 0; v4 < 4; ++v4) {
+        const uint4 u = src[v4];
+        const unsigned uu[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc += __builtin_bit_cast(float, uu[e] << 16) * wt[v4 * 8 + 2 * e];
+          acc += __builtin_bit_cast(float, uu[e] & 0xFFFF0000u) * wt[v4 * 8 + 2 * e + 1];
+        }
+      }
+    }
+  }
+  y[pix] = 1.f / (1.f + __expf(-acc));
+}
+
+// packed fp32 weights (gather [n][25][c] or parity [class][n][taps][c]) times the folded BatchNorm scale of output channel n
+// -> bf16.  cpad > c: the channels are placed at [cpad - c, cpad) of a cpad-wide K row and the rest is zero (conv2 reads the
+// interleaved 32-channel level 1 with zero weights on the decoder half).
+__global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict__ wp, const float* __restrict__ scale, u16* __restrict__ out,
+                                                        int N, int C, int cpad, int parity) {
+  const long total = (long)N * cpad * 25;
+  for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < total; o += (long)gridDim.x * 256) {
+    const int c = (int)(o % cpad);
+    const long r = o / cpad;                                  // (class, n, tap) flattened as in the fp32 packing
+    int n;
+    if (!parity) n = (int)(r / 25);
+    else {
+      const long NC = N;                                      // rows per class = N * ntaps
+      long rr = r; int ntaps = 9;
+      if (rr >= 9 * NC) { rr -= 9 * NC; ntaps = 6; if (rr >= 6 * NC) { rr -= 6 * NC; if (rr >= 6 * NC) { rr -= 6 * NC; ntaps = 4; } } }
+      n = (int)(rr / ntaps);
+    }
+    const int cs = c - (cpad - C);
+    out[o] = cs >= 0 ? to_bf16(wp[r * C + cs] * scale[n]) : (u16)0;
+  }
+}
+
+// ---- host side -----------------------------------------------------------------------------------
+struct Bf16Plan { int BM, BN, cfg, ksplit, grid_y; long mtiles; };
+static Bf16Plan plan_bf16(int mode, long Mmax, int N, int nkt) {
+  Bf16Plan pl{};
+  if (N % 128 == 0) { pl.cfg = Mmax >= 4096 ? 0 : 4; pl.BM = Mmax >= 4096 ? 128 : 64; pl.BN = 128; }
+  else if (N == 64) { pl.cfg = 1; pl.BM = 128; pl.BN = 64; }
+  else if (N == 32) { pl.cfg = 2; pl.BM = 256; pl.BN = 32; }
+  else { pl.cfg = 3; pl.BM = 256; pl.BN = 16; }
+  pl.mtiles = (Mmax + pl.BM - 1) / pl.BM;
+  pl.grid_y = mode == BF_PARITY ? 4 : 1;
+  const long blocks = pl.mtiles * (N / pl.BN) * pl.grid_y;
+  int ks = 1;
+  if (blocks < 512) {                                        // deep levels at small batch: split K to fill the chip
+    ks = (int)((768 + blocks - 1) / blocks);
+    const int cap = nkt / 8 > 1 ? nkt / 8 : 1;
+    if (ks > cap) ks = cap;
+    if (ks > 32) ks = 32;
+  }
+  pl.ksplit = ks;
+  return pl;
+}
+static size_t bf16_layer_ws(int mode, int B, int H, int W, int C, int Ho, int Wo, int N) {
+  const long Mmax = mode == BF_GATHER ? (long)B * Ho * Wo : (long)B * ((Ho + 1) / 2) * ((Wo + 1) / 2);
+  const int nkt = (mode == BF_GATHER ? 25 : 4) * (C / 32);
+  const Bf16Plan pl = plan_bf16(mode, Mmax, N, nkt);
+  return pl.ksplit > 1 ? (size_t)pl.ksplit * B * Ho * Wo * N * sizeof(float) : 0;
+}
+static int conv_bf16_run(int mode, const u16* x, long ldx, int B, int H, int W, int C, const u16* wp, const float* shift, float slope,
+                         u16* y, long ldy, int Ho, int Wo, int N, void* ws, size_t ws_bytes, hipStream_t stream) {
+  SVS_REQUIRE(C % 32 == 0 && (N == 16 || N == 32 || N == 64 || N % 128 == 0), "conv_bf16: unsupported channels C=%d N=%d", C, N);
+  SVS_REQUIRE(((long)B * H * W * ldx + 4L * (W + 2) * ldx) * 2 < (1L << 31) && (long)N * C * 25 * 2 < (1L << 31), "conv_bf16: view too large; split the batch");
+  const long Mmax = mode == BF_GATHER ? (long)B * Ho * Wo : (long)B * ((Ho + 1) / 2) * ((Wo + 1) / 2);
+  const int nkt = (mode == BF_GATHER ? 25 : 4) * (C / 32);
+  const Bf16Plan pl = plan_bf16(mode, Mmax, N, nkt);
+  ConvBf16Args a{x, ldx, B, H, W, C, wp, shift, slope, y, ldy, Ho, Wo, N, pl.ksplit, nullptr};
+  if (pl.ksplit > 1) {
+    const size_t need = (size_t)pl.ksplit * B * Ho * Wo * N * sizeof(float);
+    if (!ws || ws_bytes < need) { svs_set_error("conv_bf16: workspace too small (%zu < %zu)", ws_bytes, need); return SVS_ERR_WORKSPACE; }
+    a.slab = (float*)ws;
+  }
+  dim3 grid((unsigned)(pl.mtiles * (N / pl.BN)), (unsigned)pl.ksplit, (unsigned)pl.grid_y);
+#define SVS_BF16_LAUNCH(MODE_) \
+  switch (pl.cfg) { \
+    case 0: hipLaunchKernelGGL((conv_gemm_bf16_kernel<MODE_, 128, 128, 2, 2>), grid, dim3(256), 0, stream, a); break; \
+    case 1: hipLaunchKernelGGL((conv_gemm_bf16_kernel<MODE_, 128, 64, 2, 2>), grid, dim3(256), 0, stream, a); break; \
+    case 2: hipLaunchKernelGGL((conv_gemm_bf16_kernel<MODE_, 256, 32, 4, 1>), grid, dim3(256), 0, stream, a); break; \
+    case 3: hipLaunchKernelGGL((conv_gemm_bf16_kernel<MODE_, 256, 16, 4, 1>), grid, dim3(256), 0, stream, a); break; \
+    default: hipLaunchKernelGGL((conv_gemm_bf16_kernel<MODE_, 64, 128, 2, 2>), grid, dim3(256), 0, stream, a); break; \
+  }
+  if (mode == BF_GATHER) { SVS_BF16_LAUNCH(BF_GATHER) } else { SVS_BF16_LAUNCH(BF_PARITY) }
+#undef SVS_BF16_LAUNCH
+  SVS_CHECK_LAUNCH("conv_gemm_bf16");
+  if (pl.ksplit > 1) {
+    const long P = (long)B * Ho * Wo, total4 = P * N / 4;
+    int g = (int)((total4 + 255) / 256);
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(splitk_epilogue_bf16_kernel, dim3(g), dim3(256), 0, stream, (const float*)a.slab, pl.ksplit, P, N, shift, slope, y, ldy);
+    SVS_CHECK_LAUNCH("splitk_epilogue_bf16");
+  }
+  return SVS_OK;
+}
+
+// ---- whole network ---------------------------------------------------------------------------------
+static const int BCH[7] = {1, 16, 32, 64, 128, 256, 512};
+static const int BDEC_C[6] = {512, 512, 256, 128, 64, 32};
+static const int BDEC_N[6] = {256, 128, 64, 32, 16, 1};
+struct Bf16Prepared { long w[12], shift[11], w1, w6, bias6, total; };          // byte offsets into the prepared blob
+static Bf16Prepared bf16_prepared_layout() {
+  Bf16Prepared L{};
+  long off = 0;
+  auto take = [&](long bytes) { long o = off; off += (bytes + 255) / 256 * 256; return o; };
+  L.w1 = take(16 * 25 * 4);                                    // conv1: fp32 [16][25], scale folded
+  for (int k = 2; k <= 6; ++k) L.w[k - 1] = take((long)BCH[k] * (k == 2 ? 32 : BCH[k - 1]) * 25 * 2);
+  for (int j = 0; j < 5; ++j) L.w[6 + j] = take((long)BDEC_C[j] * BDEC_N[j] * 25 * 2);
+  L.w6 = take(32 * 25 * 4);                                    // deconv6: fp32 [32][25] (torch layout)
+  for (int l = 0; l < 11; ++l) L.shift[l] = take((l < 6 ? BCH[l + 1] : BDEC_N[l - 6]) * 4);
+  L.bias6 = take(4);
+  L.total = off;
+  return L;
+}
+extern "C" size_t svs_unet_prepared_bf16_bytes(void) { return (size_t)bf16_prepared_layout().total; }
+
+__global__ void fold_conv1_kernel(const float* __restrict__ w, const float* __restrict__ scale, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 400) out[i] = w[i] * scale[i / 25];
+}
+
+// prepared_f32: the blob of svs_unet_prepare_eval (packed fp32 weights + folded scale / shift); this adds the bf16 forms
+extern "C" int svs_unet_prepare_eval_bf16(const void* prepared_f32, void* prepared_bf16, hipStream_t stream) {
+  SVS_REQUIRE(prepared_f32 && prepared_bf16 && svs_aligned16(prepared_bf16), "svs_unet_prepare_eval_bf16: bad pointers");
+  const Bf16Prepared L = bf16_prepared_layout();
+  char* out = (char*)prepared_bf16;
+  const float* blob = (const float*)prepared_f32;
+  long wp[12], scale[11], shift[11], bias6;
+  svs_unet_prepared_offsets(wp, scale, shift, &bias6);
+  hipLaunchKernelGGL(fold_conv1_kernel, dim3(2), dim3(256), 0, stream, blob + wp[0], blob + scale[0], (float*)(out + L.w1));
+  SVS_CHECK_LAUNCH("fold_conv1");
+  for (int k = 2; k <= 6; ++k) {
+    const int N = BCH[k], C = BCH[k - 1], cpad = k == 2 ? 32 : C;
+    hipLaunchKernelGGL(pack_bf16_kernel, dim3(512), dim3(256), 0, stream, blob + wp[k - 1], blob + scale[k - 1], (u16*)(out + L.w[k - 1]), N, C, cpad, 0);
+    SVS_CHECK_LAUNCH("pack_bf16");
+  }
+  for (int j = 0; j < 5; ++j) {
+    hipLaunchKernelGGL(pack_bf16_kernel, dim3(512), dim3(256), 0, stream, blob + wp[6 + j], blob + scale[6 + j], (u16*)(out + L.w[6 + j]), BDEC_N[j],
+                       BDEC_C[j], BDEC_C[j], 1);
+    SVS_CHECK_LAUNCH("pack_bf16");
+  }
+  SVS_HIP(hipMemcpyAsync(out + L.w6, blob + wp[11], 32 * 25 * 4, hipMemcpyDeviceToDevice, stream));
+  SVS_HIP(hipMemcpyAsync(out + L.bias6, blob + bias6, 4, hipMemcpyDeviceToDevice, stream));
+  for (int l = 0; l < 11; ++l)
+    SVS_HIP(hipMemcpyAsync(out + L.shift[l], blob + shift[l], (l < 6 ? BCH[l + 1] : BDEC_N[l - 6]) * 4, hipMemcpyDeviceToDevice, stream));
+  return SVS_OK;
+}
+
+struct Bf16Ws { u16* cat[6]; u16* c6; void* scratch; size_t scratch_bytes; size_t total; int h[7], w[7]; long P[7]; };
+static int bf16_ws_layout(int B, int H, int W, void* ws, Bf16Ws& e) {
+  SVS_REQUIRE(B > 0 && H > 0 && W > 0, "bad tile geometry B=%d H=%d W=%d", B, H, W);
+  e.h[0] = H; e.w[0] = W;
+  for (int k = 1; k <= 6; ++k) { e.h[k] = svs_conv_out(e.h[k - 1]); e.w[k] = svs_conv_out(e.w[k - 1]); }
+  for (int k = 0; k <= 6; ++k) e.P[k] = (long)B * e.h[k] * e.w[k];
+  size_t used = 0;
+  auto take = [&](size_t bytes) { void* p = ws ? (char*)ws + used : nullptr; used += svs_align_up(bytes, 256); return p; };
+  for (int k = 1; k <= 5; ++k) e.cat[k] = (u16*)take((size_t)e.P[k] * 2 * BCH[k] * 2);
+  e.c6 = (u16*)take((size_t)e.P[6] * 512 * 2);
+  size_t sb = 0;
+  for (int k = 2; k <= 6; ++k) { const size_t s = bf16_layer_ws(BF_GATHER, B, e.h[k - 1], e.w[k - 1], k == 2 ? 32 : BCH[k - 1], e.h[k], e.w[k], BCH[k]); if (s > sb) sb = s; }
+  for (int j = 0; j < 5; ++j) { const size_t s = bf16_layer_ws(BF_PARITY, B, e.h[6 - j], e.w[6 - j], BDEC_C[j], e.h[5 - j], e.w[5 - j], BDEC_N[j]); if (s > sb) sb = s; }
+  e.scratch_bytes = sb;
+  e.scratch = take(sb + 256);
+  e.total = used;
+  return SVS_OK;
+}
+extern "C" size_t svs_unet_eval_bf16_workspace_bytes(int B, int H, int W) {
+  Bf16Ws e;
+  if (bf16_ws_layout(B, H, W, nullptr, e)) return 0;
+  return e.total;
+}
+
+extern "C" int svs_unet_forward_eval_bf16(const void* prepared_bf16, const float* mix, float* mask, int B, int H, int W, void* ws,
+                                          size_t ws_bytes, hipStream_t stream) {
+  Bf16Ws e;
+  int rc = bf16_ws_layout(B, H, W, ws, e);
+  if (rc) return rc;
+  SVS_REQUIRE(prepared_bf16 && mix && mask && svs_aligned16(mix) && svs_aligned16(mask), "svs_unet_forward_eval_bf16: bad pointers");
+  if (!ws || ws_bytes < e.total || !svs_aligned16(ws)) { svs_set_error("svs_unet_forward_eval_bf16: workspace too small (%zu < %zu)", ws_bytes, e.total); return SVS_ERR_WORKSPACE; }
+  const Bf16Prepared L = bf16_prepared_layout();
+  const char* blob = (const char*)prepared_bf16;
+  auto SH = [&](int l) { return (const float*)(blob + L.shift[l]); };
+  // encoder (model.py:176-181).  Level 1 is [decoder 16 | skip 16]: conv2 multiplies the decoder half by zero weights, so it
+  // must hold finite numbers -- conv1 writes zeros there
+  hipLaunchKernelGGL(conv1_bf16_kernel, dim3((unsigned)((e.P[1] + 255) / 256)), dim3(256), 0, stream, mix, B, H, W, (const float*)(blob + L.w1), SH(0), 0.2f,
+                     e.cat[1], 32L, e.h[1], e.w[1]);
+  SVS_CHECK_LAUNCH("conv1_bf16");
+  for (int k = 2; k <= 6; ++k) {
+    const int C = k == 2 ? 32 : BCH[k - 1];
+    const u16* x = k == 2 ? e.cat[1] : e.cat[k - 1] + BCH[k - 1];        // skip half (second) of the level below; level 1: all 32 (see above)
+    const long ldx = 2L * BCH[k - 1];
+    u16* y = k == 6 ? e.c6 : e.cat[k] + BCH[k];
+    const long ldy = k == 6 ? 512 : 2L * BCH[k];
+    if ((rc = conv_bf16_run(BF_GATHER, x, ldx, B, e.h[k - 1], e.w[k - 1], C, (const u16*)(blob + L.w[k - 1]), SH(k - 1), 0.2f, y, ldy, e.h[k], e.w[k],
+                            BCH[k], e.scratch, e.scratch_bytes, stream))) return rc;
+  }
+  // decoder (model.py:183-196); Dropout2d is the identity in eval
+  for (int j = 0; j < 5; ++j) {
+    const int lin = 6 - j, lout = 5 - j;
+    const u16* x = j == 0 ? e.c6 : e.cat[lin];
+    if ((rc = conv_bf16_run(BF_PARITY, x, BDEC_C[j], B, e.h[lin], e.w[lin], BDEC_C[j], (const u16*)(blob + L.w[6 + j]), SH(6 + j), 0.f, e.cat[lout],
+                            2L * BCH[lout], e.h[lout], e.w[lout], BDEC_N[j], e.scratch, e.scratch_bytes, stream))) return rc;
+  }
+  // deconv6 + sigmoid (model.py:198-200)
+  hipLaunchKernelGGL(deconv6_bf16_kernel, dim3((unsigned)((e.P[0] + 255) / 256)), dim3(256), 0, stream, e.cat[1], 32L, B, e.h[1], e.w[1],
+                     (const float*)(blob + L.w6), (const float*)(blob + L.bias6), mask, H, W);
+  SVS_CHECK_LAUNCH("deconv6_bf16");
+  return SVS_OK;
+}

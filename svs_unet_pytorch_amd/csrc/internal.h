@@ -54,3 +54,6 @@ int svs_bn_bwd_run(const float* dy, long lddy, const float* raw, long ldr, long 
 
 int svs_conv_gemm_describe(int mode, int B, int H, int W, int C, int Ho, int Wo, int N, long ldx, char* buf, size_t n);
 int svs_wgrad_gemm_describe(int B, int Hs, int Ws, int Cs, int Cl, char* buf, size_t n);
+
+// float offsets of the pieces of the fp32 eval blob (svs_unet_prepare_eval): packed weights, folded BatchNorm scale / shift
+void svs_unet_prepared_offsets(long wp[12], long scale[11], long shift[11], long* bias6);

@@ -246,6 +246,12 @@ static Prepared prepared_layout() {
   p.total = off;
   return p;
 }
+void svs_unet_prepared_offsets(long wp[12], long scale[11], long shift[11], long* bias6) {
+  const Prepared L = prepared_layout();
+  for (int l = 0; l < 12; ++l) wp[l] = L.wp[l];
+  for (int l = 0; l < 11; ++l) { scale[l] = L.scale[l]; shift[l] = L.shift[l]; }
+  *bias6 = L.bias6;
+}
 extern "C" size_t svs_unet_prepared_bytes(void) { return (size_t)prepared_layout().total * sizeof(float); }
 
 extern "C" int svs_unet_prepare_eval(const float* params, const float* bn_buffers, void* prepared, hipStream_t stream) {

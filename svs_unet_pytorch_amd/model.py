@@ -212,6 +212,9 @@ class UNet(nn.Module):
         self._xstream = None            # stream the overlapped gradient exchange is issued from
         self.dropout_step = 0
         self.last_mr_loss = None        # MR-STFT part of the last training objective (device scalar) or None
+        self.eval_precision = "fp32"    # "bf16": eval forwards run the bf16-MFMA network (BASELINE configs[4]); training is fp32
+        self._prepared_bf16 = None
+        self._prepared_bf16_key = None
         self.rank = 0
         self._flatten()
 
@@ -324,7 +327,8 @@ class UNet(nn.Module):
         key = (kind, B, H, W)
         ws = self._ws.get(key)
         if ws is None:
-            fn = lib().svs_unet_eval_workspace_bytes if kind == "eval" else lib().svs_unet_train_workspace_bytes
+            fn = {"eval": lib().svs_unet_eval_workspace_bytes, "eval_bf16": lib().svs_unet_eval_bf16_workspace_bytes,
+                  "train": lib().svs_unet_train_workspace_bytes}[kind]
             nbytes = int(fn(B, H, W))
             ws = torch.empty(nbytes, dtype=torch.uint8, device=self._flat.device)
             if len(self._ws) > 8:
@@ -359,8 +363,21 @@ class UNet(nn.Module):
             check(lib().svs_unet_prepare_eval(ptr(self._flat), ptr(self._bn_flat), ptr(self._prepared), _lib.stream_ptr()),
                   "svs_unet_prepare_eval")
             self._prepared_key = key
-        ws = self._workspace("eval", B, H, W)
         mask = torch.empty_like(mix)
+        if self.eval_precision == "bf16":
+            if self._prepared_bf16 is None or self._prepared_bf16_key != key:
+                if self._prepared_bf16 is None or self._prepared_bf16.device != self._flat.device:
+                    self._prepared_bf16 = torch.empty(int(lib().svs_unet_prepared_bf16_bytes()), dtype=torch.uint8, device=self._flat.device)
+                check(lib().svs_unet_prepare_eval_bf16(ptr(self._prepared), ptr(self._prepared_bf16), _lib.stream_ptr()),
+                      "svs_unet_prepare_eval_bf16")
+                self._prepared_bf16_key = key
+            ws = self._workspace("eval_bf16", B, H, W)
+            check(lib().svs_unet_forward_eval_bf16(ptr(self._prepared_bf16), ptr(mix), ptr(mask), B, H, W, ptr(ws), ws.numel(),
+                                                   _lib.stream_ptr()), "svs_unet_forward_eval_bf16")
+            return mask
+        if self.eval_precision != "fp32":
+            raise ValueError(f"eval_precision must be 'fp32' or 'bf16', got {self.eval_precision!r}")
+        ws = self._workspace("eval", B, H, W)
         check(lib().svs_unet_forward_eval(ptr(self._prepared), ptr(mix), ptr(mask), B, H, W, ptr(ws), ws.numel(),
                                           _lib.stream_ptr()), "svs_unet_forward_eval")
         return mask

@@ -46,7 +46,7 @@ def separate_spectrogram_device(model, mag: torch.Tensor, seg_len: int = INPUT_L
 
 @torch.no_grad()
 def separate_waveform(model, y: torch.Tensor, vocal_solo: bool = True, n_fft: int = WINDOW_SIZE, hop: int = HOP_SIZE,
-                      peak: float | None = 0.9, max_batch: int = 256):
+                      peak: float | None = 0.9, max_batch: int = 256, precision: str | None = None):
     """float32 samples (n,) or (channels, n) on the GPU -> separated samples (hop*(T-1),) or (channels, hop*(T-1)).
     All channels go through ONE forward transform (which writes network tiles and frame-major phasors directly), one
     batched network forward per `max_batch` tiles and ONE inverse transform (which applies the mask on load and
@@ -61,10 +61,13 @@ def separate_waveform(model, y: torch.Tensor, vocal_solo: bool = True, n_fft: in
         _lib.check(L.svs_scale_by_inv(tiles[c].data_ptr(), tiles[c].numel(), norm[c:].data_ptr(), 1.0, _lib.stream_ptr()), "svs_scale_by_inv")
     flat = tiles.view(C * n_tiles, 1, tiles.shape[3], tiles.shape[4])
     mask = torch.empty_like(flat)
-    was_training = model.training
+    was_training, was_precision = model.training, model.eval_precision
     model.eval()
+    if precision is not None:                                    # "bf16": the convolutions run on the bf16 MFMA (configs[4])
+        model.eval_precision = precision
     for s in range(0, flat.shape[0], max_batch):
         mask[s:s + max_batch] = model(flat[s:s + max_batch])
+    model.eval_precision = was_precision
     model.train(was_training)
     out = istft_from_tiles(tiles, mask, phase, T, invert=not vocal_solo, n_fft=n_fft, hop=hop, peak=peak)
     return out[0] if squeeze else out

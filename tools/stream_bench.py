@@ -23,6 +23,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=240.0)
     ap.add_argument("--rate", type=int, default=44100)
+    ap.add_argument("--precision", default="fp32", choices=("fp32", "bf16"))
     a = ap.parse_args()
     n = int(a.seconds * a.rate)
     model = UNet()
@@ -30,17 +31,17 @@ def main():
     model.to("cuda").eval()
     y = torch.from_numpy(np.stack([synth.audio(n, 20), synth.audio(n, 21)])).to("cuda")
     for _ in range(2):
-        out = separate_waveform(model, y)
+        out = separate_waveform(model, y, precision=a.precision)
     torch.cuda.synchronize()
     reps = 5
     t0 = time.perf_counter()
     for _ in range(reps):
-        out = separate_waveform(model, y)
+        out = separate_waveform(model, y, precision=a.precision)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     frames = 1 + n // 768
     tiles = 2 * ((frames + 127) // 128)
-    print(f"{a.seconds:.0f} s of stereo audio at {a.rate} Hz ({tiles} tiles): {dt * 1e3:.2f} ms end to end = "
+    print(f"[{a.precision}] {a.seconds:.0f} s of stereo audio at {a.rate} Hz ({tiles} tiles): {dt * 1e3:.2f} ms end to end = "
           f"{a.seconds / dt:.0f}x real time, {tiles / dt:.0f} tiles/s incl. STFT / iSTFT; output {tuple(out.shape)}")
 
 
