@@ -30,8 +30,10 @@ static const int MR_WIN[MR_NRES] = {600, 1200, 240};
 #define MR_EPS 1e-8f
 
 // waves (= independent transforms) per block: the LDS of eight 2048-point buffers would exceed 160 KB
-template <int N> struct MrCfg { static constexpr int WAVES = (N == 2048) ? 4 : 8; };
-static int mr_waves(int n) { return n == 2048 ? 4 : 8; }
+// (no window table in LDS either -- the window is one v_cos_f32 per sample -- so that 1024-point blocks (8 waves, 78 KB) and
+// 2048-point blocks (3 waves, 69 KB) fit twice per CU)
+template <int N> struct MrCfg { static constexpr int WAVES = (N == 2048) ? 3 : 8; };
+static int mr_waves(int n) { return n == 2048 ? 3 : 8; }
 
 struct MrArgs {
   const float* x; const float* y; int B; long L;     // predicted / target waveforms (B, L)
@@ -41,26 +43,26 @@ struct MrArgs {
   float* frames;                                     // [B][F][N] windowed frame gradients
 };
 
+// periodic Hann window of `win` samples centred inside n_fft (torch.stft pads a short window on both sides), sample m;
+// v_cos_f32 takes revolutions (absolute error ~1e-6, far below the loss tolerance)
 template <int N>
-__device__ __forceinline__ void mr_window(float* wfull, int win, int tid, int nthreads) {
-  const int off = (N - win) / 2;                     // torch.stft centres a short window inside n_fft
-  for (int m = tid; m < N; m += nthreads) {
-    const int j = m - off;
-    wfull[m] = (j >= 0 && j < win) ? 0.5f - 0.5f * cospif(2.0f * (float)j / (float)win) : 0.f;
-  }
+__device__ __forceinline__ float mr_window(int m, int win, float inv_win) {
+  const int j = m - (N - win) / 2;
+  return (j >= 0 && j < win) ? 0.5f - 0.5f * __builtin_amdgcn_cosf((float)j * inv_win) : 0.f;
 }
 __device__ __forceinline__ long mr_reflect(long p, long L) { return p < 0 ? -p : (p >= L ? 2 * (L - 1) - p : p); }
 
 // frame t of x (real part) and y (imaginary part), windowed, into the wave's buffer
 template <int N>
-__device__ __forceinline__ void mr_fill(float2* buf, const float* wfull, const MrArgs& p, int b, int t, int lane) {
+__device__ __forceinline__ void mr_fill(float2* buf, const MrArgs& p, int b, int t, int lane) {
+  const float inv_win = 1.0f / (float)p.win;
 #pragma unroll 4
   for (int r = 0; r < N / 64; ++r) {
     const int m = lane + 64 * r;
     float2 v = float2{0.f, 0.f};
     if (t < p.F) {
       const long s = mr_reflect((long)t * p.hop + m - N / 2, p.L);
-      const float w = wfull[m];
+      const float w = mr_window<N>(m, p.win, inv_win);
       v = float2{p.x[(long)b * p.L + s] * w, p.y[(long)b * p.L + s] * w};
     }
     buf[fft_pad(m)] = v;
@@ -78,15 +80,13 @@ __global__ __launch_bounds__(64 * MrCfg<N>::WAVES) void mr_sums_kernel(MrArgs p)
   constexpr int BUF = FftSize<N>::BUF, TW = FftSize<N>::TW, WV = MrCfg<N>::WAVES;
   float2* const fbuf = (float2*)smem;
   float2* const tw = fbuf + WV * BUF;
-  float* const wfull = (float*)(tw + TW);
-  float* const red = wfull + N;                      // [WV][3]
+  float* const red = (float*)(tw + TW);              // [WV][3]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.y, t = blockIdx.x * WV + wave;
   fft_build_twiddles<N>(tw, tid, 64 * WV);
-  mr_window<N>(wfull, p.win, tid, 64 * WV);
-  __syncthreads();
   float2* const buf = fbuf + wave * BUF;
-  mr_fill<N>(buf, wfull, p, b, t, lane);
+  mr_fill<N>(buf, p, b, t, lane);
+  __syncthreads();
   fft_wave<N>(buf, tw, lane);
   float s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (t < p.F) {
@@ -96,11 +96,14 @@ __global__ __launch_bounds__(64 * MrCfg<N>::WAVES) void mr_sums_kernel(MrArgs p)
       if (k > N / 2) continue;
       float2 X, Y;
       mr_split(buf[fft_pad(k)], buf[fft_pad((N - k) & (N - 1))], X, Y);
-      const float xm = sqrtf(fmaxf(X.x * X.x + X.y * X.y, MR_EPS)), ym = sqrtf(fmaxf(Y.x * Y.x + Y.y * Y.y, MR_EPS));
+      // one-instruction sqrt / log2 (v_sqrt_f32, v_log_f32: ~1 ulp): the kernel is VALU-bound, and |log|X| - log|Y|| =
+      // (ln 2 / 2) |log2 |X|^2 - log2 |Y|^2| needs no square root at all
+      const float x2 = fmaxf(X.x * X.x + X.y * X.y, MR_EPS), y2 = fmaxf(Y.x * Y.x + Y.y * Y.y, MR_EPS);
+      const float xm = __builtin_amdgcn_sqrtf(x2), ym = __builtin_amdgcn_sqrtf(y2);
       const float d = ym - xm;
       s1 += d * d;
-      s2 += ym * ym;
-      s3 += fabsf(logf(xm) - logf(ym));
+      s2 += y2;
+      s3 += 0.34657359027997264f * fabsf(__builtin_amdgcn_logf(x2) - __builtin_amdgcn_logf(y2));
     }
   }
   s1 = svs_wave_sum(s1); s2 = svs_wave_sum(s2); s3 = svs_wave_sum(s3);
@@ -151,11 +154,9 @@ __global__ __launch_bounds__(64 * MrCfg<N>::WAVES) void mr_grad_kernel(MrArgs p)
   constexpr int BUF = FftSize<N>::BUF, TW = FftSize<N>::TW, NR = N / 128 + 1, WV = MrCfg<N>::WAVES;
   float2* const fbuf = (float2*)smem;
   float2* const tw = fbuf + WV * BUF;
-  float* const wfull = (float*)(tw + TW);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.y, ta = blockIdx.x * (2 * WV) + 2 * wave;
   fft_build_twiddles<N>(tw, tid, 64 * WV);
-  mr_window<N>(wfull, p.win, tid, 64 * WV);
   __syncthreads();
   if (ta >= p.F) return;                             // (no barriers below: waves are independent)
   float2* const buf = fbuf + wave * BUF;
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(64 * MrCfg<N>::WAVES) void mr_grad_kernel(MrArgs p)
   float2 H[2][NR];                                   // Hermitian-weighted dL/dX of frames ta, ta + 1
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    mr_fill<N>(buf, wfull, p, b, ta + h, lane);
+    mr_fill<N>(buf, p, b, ta + h, lane);
     fft_wave<N>(buf, tw, lane);
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
@@ -174,11 +175,12 @@ __global__ __launch_bounds__(64 * MrCfg<N>::WAVES) void mr_grad_kernel(MrArgs p)
         mr_split(buf[fft_pad(k)], buf[fft_pad((N - k) & (N - 1))], X, Y);
         const float x2 = X.x * X.x + X.y * X.y;
         if (x2 > MR_EPS) {                           // clamp(min=eps) passes no gradient below eps
-          const float xm = sqrtf(x2), ym = sqrtf(fmaxf(Y.x * Y.x + Y.y * Y.y, MR_EPS));
-          const float dl = logf(xm) - logf(ym);
-          const float gm = -csc * (ym - xm) + clog * (dl > 0.f ? 1.f : (dl < 0.f ? -1.f : 0.f)) / xm;   // dL/d|X|
+          const float y2 = fmaxf(Y.x * Y.x + Y.y * Y.y, MR_EPS);
+          const float xm = __builtin_amdgcn_sqrtf(x2), ym = __builtin_amdgcn_sqrtf(y2), ix = __builtin_amdgcn_rcpf(xm);
+          // sign(log|X| - log|Y|) = sign(|X|^2 - |Y|^2)
+          const float gm = -csc * (ym - xm) + clog * (x2 > y2 ? 1.f : (x2 < y2 ? -1.f : 0.f)) * ix;   // dL/d|X|
           const bool edge = (k == 0 || k == N / 2);
-          const float wgt = (edge ? 1.0f : 0.5f) * gm / xm;
+          const float wgt = (edge ? 1.0f : 0.5f) * gm * ix;
           g = float2{wgt * X.x, edge ? 0.f : wgt * X.y};
         }
       }
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(64 * MrCfg<N>::WAVES) void mr_grad_kernel(MrArgs p)
   for (int r = 0; r < N / 64; ++r) {
     const int m = lane + 64 * r;
     const float2 z = buf[fft_pad(m)];
-    const float w = wfull[m];
+    const float w = mr_window<N>(m, p.win, 1.0f / (float)p.win);
     fa[m] = z.x * w;
     if (ta + 1 < p.F) fa[N + m] = -z.y * w;
   }
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(256) void mr_ola_kernel(MrOlaArgs a) {
 }
 
 // ---- host side -----------------------------------------------------------------------------------
-template <int N> static size_t mr_lds_bytes() { return (size_t)MrCfg<N>::WAVES * FftSize<N>::BUF * 8 + FftSize<N>::TW * 8 + N * 4 + 8 * 3 * 4 + 64; }
+template <int N> static size_t mr_lds_bytes() { return (size_t)MrCfg<N>::WAVES * FftSize<N>::BUF * 8 + FftSize<N>::TW * 8 + 8 * 3 * 4 + 32; }
 struct MrWs { float* partial[MR_NRES]; int nblk[MR_NRES]; float* frames[MR_NRES]; float* coef; size_t total; };
 static MrWs mr_layout(int B, long L, void* ws) {
   MrWs w{};
