@@ -14,6 +14,8 @@
 // Level 1 is interleaved here ([decoder 16 | skip 16] = one 64-byte line per pixel): conv2 reads all 32 channels with zero
 // weights on the decoder half (which is therefore zero-filled at the start of a forward), so that no layer needs a 16-wide
 // K-tile.  Bound: HBM / launch at streaming batch sizes (bf16 MFMA peak ~2.5 PFLOP/s: 16x the fp32 rate).
+#include <type_traits>
+
 #include "internal.h"
 
 typedef unsigned short u16;
@@ -184,6 +186,176 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_kernel(ConvBf16Args p) {
     }
 }
 
+
+template <int N_, int I_ = 0, class F>
+__device__ __forceinline__ void bf_static_for(F&& f) {          // f(integral_constant<int, I>) for I = 0 .. N-1, unrolled
+  if constexpr (I_ < N_) {
+    f(std::integral_constant<int, I_>{});
+    bf_static_for<N_, I_ + 1>(f);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS-window form of the PARITY mode for the shallow decoder layers (deconv4: 128 -> 32, deconv5: 64 -> 16 channels; 2/3 of
+// the bf16 forward's time in the GEMM form: with 16 / 32 output channels an im2col element feeds one or two MFMAs, so the
+// GEMM is bound by moving each input element ~6 times through L2 / LDS, not by the MFMA).  A block owns 8 x 16 anchor
+// pixels of one image (= a 16 x 32 output patch, all four parity classes), stages that window plus a one-pixel halo ONCE
+// (zero-filled outside the image; pixel pitch 2C + 16 bytes: conflict-free ds_read_b128), and every tap of every class
+// reads its A fragments at base + compile-time offset.  Weight fragments come from global memory (shared by all blocks:
+// L2-resident), one tap ahead.  Same structure as parity_window_kernel of gemm_conv.hip; one MFMA covers 32 channels.
+// ------------------------------------------------------------------------------------------------
+template <int C, int TN>
+__global__ __launch_bounds__(256) void parity_window_bf16_kernel(ConvBf16Args p) {
+  constexpr int TH = 8, TW = 16, TM = 2;
+  constexpr int LPB = C * 2 + 16;                               // bytes per staged pixel
+  constexpr int WW = TW + 2, NPX = (TH + 2) * WW;
+  constexpr int CQ = C / 8, CC = C / 32;
+  constexpr int NST = (NPX * CQ + 255) / 256;
+  constexpr unsigned OOB = 0x80000000u;
+  constexpr int POFF[4] = {0, 9, 15, 21};
+  __shared__ __attribute__((aligned(16))) unsigned char win[NPX * LPB];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int lrow = lane & 15, q = lane >> 4;
+  const int tiles_w = (p.W + TW - 1) / TW, tiles_h = (p.H + TH - 1) / TH;
+  const int ntiles = p.B * tiles_h * tiles_w;
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, OOB, 0x00020000);
+  // persistent blocks: a block walks tiles blockIdx.x, + gridDim.x, ... so that resident weights (WALL) are fetched once per
+  // block instead of once per tile (51 KB per 128 anchors was most of the L2 traffic)
+  int th0 = 0, tw0 = 0;
+  long b = 0;
+  auto stage_window = [&](int tile) {
+    tw0 = (tile % tiles_w) * TW;
+    th0 = ((tile / tiles_w) % tiles_h) * TH;
+    b = tile / (tiles_w * tiles_h);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + b * p.H * p.W * p.ldx), 0, OOB, 0x00020000);
+    f32x4 stage[NST];
+#pragma unroll
+    for (int k = 0; k < NST; ++k) {
+      const int e = t + k * 256;
+      const int cq = e % CQ, px = e / CQ;
+      const int lw = px % WW, lh = px / WW;
+      const int ih = th0 - 1 + lh, iw = tw0 - 1 + lw;
+      const bool ok = px < NPX && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+      const unsigned vo = ok ? (unsigned)(((ih * p.W + iw) * (int)p.ldx + cq * 8) * 2) : OOB;
+      stage[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)vo, 0, 0));
+    }
+#pragma unroll
+    for (int k = 0; k < NST; ++k) {
+      const int e = t + k * 256;
+      const int cq = e % CQ, px = e / CQ;
+      if (px < NPX) *(f32x4*)(&win[px * LPB + cq * 16]) = stage[k];
+    }
+  };
+  // A fragment of row tile i: anchor (2 wave + i, lrow) at window coordinate (+1, +1), 16-byte chunk q of a 32-channel step
+  const unsigned char* abase = &win[((2 * wave + 1) * WW + lrow + 1) * LPB + q * 16];
+  // Weights of one tap ([n][C] bf16, N * C * 2 bytes) are brought into LDS ONCE per block and tap (double-buffered, one
+  // barrier per tap) and every wave reads its B fragments from there: fetched per wave from L2 they were 4x the traffic
+  // (1.4 GB per launch at 216 tiles -- the L2, not the MFMA, set the kernel's time).
+  constexpr int N = TN * 16, WCH = N * CQ;                         // 16-byte pieces per tap
+  constexpr int NWL = (WCH + 255) / 256;
+  // weight row pitch: padded by 16 bytes, or -- when all 25 taps are resident and the padding would cost the second block
+  // per CU -- unpadded with the 16-byte pieces XOR-swizzled by the row (2-way conflicts instead of 16-way)
+  constexpr bool WSWZ = 25 * N * (C * 2 + 16) <= 60 * 1024;
+  constexpr int WPB = WSWZ ? C * 2 : C * 2 + 16;
+  auto wpos = [](int n, int piece) { return WSWZ ? (piece ^ (n & 7)) : piece; };
+  // deconv5's 25 taps are 51 KB in all: they are staged once, up front, and the tap loop has no barriers at all (with 4 MFMAs
+  // per wave and tap a barrier per tap cost more than the MFMAs); deconv4's 205 KB go through two per-tap buffers
+  constexpr bool WALL = WSWZ;
+  constexpr int NBUF = WALL ? 25 : 2;
+  __shared__ __attribute__((aligned(16))) unsigned char wts[NBUF][N * WPB];
+  f32x4 wreg[NWL];
+  auto fetch_w = [&](auto sc) {                                     // global -> registers: weights of step sc
+    constexpr int s_ = decltype(sc)::value;
+    constexpr int par = s_ < 9 ? 0 : s_ < 15 ? 1 : s_ < 21 ? 2 : 3;
+    constexpr int tap = s_ - POFF[par];
+    constexpr int ntaps = (3 - (par >> 1)) * (3 - (par & 1));
+#pragma unroll
+    for (int k = 0; k < NWL; ++k) {
+      const int e = t + k * 256, n = e / CQ, cq = e - n * CQ;
+      const unsigned vo = e < WCH ? (unsigned)((n * ntaps * C + cq * 8) * 2) : OOB;
+      wreg[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (int)vo, (POFF[par] * N * C + tap * C) * 2, 0));
+    }
+  };
+  auto stash_w = [&](int buf) {
+#pragma unroll
+    for (int k = 0; k < NWL; ++k) {
+      const int e = t + k * 256, n = e / CQ, cq = e - n * CQ;
+      if (e < WCH) *(f32x4*)(&wts[buf][n * WPB + wpos(n, cq) * 16]) = wreg[k];
+    }
+  };
+  auto step = [&](auto sc, f32x4 (&acc)[TM][TN]) {
+    constexpr int s_ = decltype(sc)::value;
+    constexpr int par = s_ < 9 ? 0 : s_ < 15 ? 1 : s_ < 21 ? 2 : 3;
+    constexpr int tap = s_ - POFF[par];
+    constexpr int ntw = 3 - (par & 1);
+    constexpr int th = tap / ntw, tw = tap % ntw;
+    constexpr int aoff = ((1 - th) * WW + (1 - tw)) * LPB;
+    const unsigned char* wb = &wts[WALL ? s_ : (s_ & 1)][lrow * WPB];
+#pragma unroll
+    for (int cc = 0; cc < CC; ++cc) {
+      bf16x8 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = __builtin_bit_cast(bf16x8, *(const f32x4*)(abase + aoff + i * WW * LPB + cc * 64));
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j] = __builtin_bit_cast(bf16x8, *(const f32x4*)(wb + j * 16 * WPB + wpos(lrow, cc * 4 + q) * 16));
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+  };
+  // rows q*4 + r of row tile i = anchor (th0 + 2 wave + i, tw0 + q*4 + r); column lrow (+16 j) = output channel
+  auto store_class = [&](int par, const f32x4 (&acc)[TM][TN]) {
+    const int ph = par >> 1, pw = par & 1;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int a = th0 + 2 * wave + i, oh = 2 * a + ph;
+      if (a >= p.H || oh >= p.Ho) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = tw0 + q * 4 + r, ow = 2 * c + pw;
+        if (c >= p.W || ow >= p.Wo) continue;
+        const long opix = (b * p.Ho + oh) * p.Wo + ow;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int n = j * 16 + lrow;
+          float v = acc[i][j][r] + p.shift[n];
+          v = v > 0.f ? v : v * p.slope;
+          p.y[opix * p.ldy + n] = to_bf16(v);
+        }
+      }
+    }
+  };
+  f32x4 acc[TM][TN];
+  if constexpr (WALL) bf_static_for<25>([&](auto sc) { fetch_w(sc); stash_w(decltype(sc)::value); });
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  __syncthreads();                             // the previous tile's readers are done with the window (and weight buffers)
+  stage_window(tile);
+  if constexpr (!WALL) {
+    fetch_w(std::integral_constant<int, 0>{});
+    stash_w(0);
+  }
+  __syncthreads();
+  bf_static_for<25>([&](auto sc) {
+    constexpr int s_ = decltype(sc)::value;
+    constexpr int par = s_ < 9 ? 0 : s_ < 15 ? 1 : s_ < 21 ? 2 : 3;
+    if constexpr (s_ == POFF[par]) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    if constexpr (!WALL && s_ + 1 < 25) fetch_w(std::integral_constant<int, (s_ + 1 < 25 ? s_ + 1 : 0)>{});   // in flight during this tap's MFMAs
+    step(sc, acc);
+    if constexpr (s_ == 24 || s_ + 1 == POFF[par < 3 ? par + 1 : 3]) store_class(par, acc);
+    if constexpr (!WALL && s_ + 1 < 25) {
+      stash_w((s_ + 1) & 1);                   // the other buffer: its last readers passed the barrier that ended tap s - 1
+      __syncthreads();
+    }
+  });
+  }
+}
+
 // out[pix][n] = bf16(act(sum_z slab[z][pix][n] + shift[n]))
 __global__ __launch_bounds__(256) void splitk_epilogue_bf16_kernel(const float* __restrict__ slab, int ksplit, long P, int N,
                                                                    const float* __restrict__ shift, float slope, u16* y, long ldy) {
@@ -336,6 +508,17 @@ static int conv_bf16_run(int mode, const u16* x, long ldx, int B, int H, int W, 
   const int nkt = (mode == BF_GATHER ? 25 : 4) * (C / 32);
   const Bf16Plan pl = plan_bf16(mode, Mmax, N, nkt);
   ConvBf16Args a{x, ldx, B, H, W, C, wp, shift, slope, y, ldy, Ho, Wo, N, pl.ksplit, nullptr};
+  // shallow decoder layers: LDS-window kernel (whenever its tiles fill the chip)
+  const long wtiles = (long)B * ((H + 7) / 8) * ((W + 15) / 16);
+  if (mode == BF_PARITY && ((C == 128 && N == 32) || (C == 64 && N == 16)) && H >= 8 && W >= 16 && wtiles >= 128 &&
+      (long)H * W * ldx * 2 < (1L << 31) && svs_tune(SVS_TUNE_CONV_WINDOW) != 0) {
+    a.ksplit = 1;
+    const unsigned wgrid = (unsigned)(wtiles < 512 ? wtiles : 512);      // persistent: two blocks per CU
+    if (C == 128) hipLaunchKernelGGL((parity_window_bf16_kernel<128, 2>), dim3(wgrid), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((parity_window_bf16_kernel<64, 1>), dim3(wgrid), dim3(256), 0, stream, a);
+    SVS_CHECK_LAUNCH("parity_window_bf16");
+    return SVS_OK;
+  }
   if (pl.ksplit > 1) {
     const size_t need = (size_t)pl.ksplit * B * Ho * Wo * N * sizeof(float);
     if (!ws || ws_bytes < need) { svs_set_error("conv_bf16: workspace too small (%zu < %zu)", ws_bytes, need); return SVS_ERR_WORKSPACE; }
