@@ -47,7 +47,7 @@ int svs_version(void);
 const char* svs_last_error_string(void);
 /* Planner overrides for sweeps, A/B runs and tests -- never needed in production.  `name` is one of CONV_CFG,
  * CONV_KSPLIT, CONV_WINDOW, CONV_SKIP, CONV_KORDER, CONV_DIRECT, SKIP_REDUCE, WGRAD_CFG, WGRAD_KSPLIT, WGRAD_SKIP,
- * WGRAD_WINDOW, WGRAD_C1_VALU, SIDE_PRIORITY, TRAIN_UNFUSED, TRAIN_ONE_STREAM, BWD_STATS, or "*" for all; value -1 = planner
+ * WGRAD_WINDOW, WGRAD_C1_VALU, SIDE_PRIORITY, TRAIN_UNFUSED, TRAIN_ONE_STREAM, or "*" for all; value -1 = planner
  * default.  The table is initialised once from the environment (SVS_<NAME>); no call path reads the environment. */
 int svs_tuning_set(const char* name, long value);
 

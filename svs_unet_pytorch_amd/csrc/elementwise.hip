@@ -73,14 +73,12 @@ __global__ __launch_bounds__(256) void channel_reduce_kernel(BnCtx p, float* __r
 
 // Sums the per-workgroup partials ws[blk][2][C] of 4 adjacent channels with one 256-thread block
 // (double accumulation, fixed order: reproducible).  Result: lane k (<4) of wave 0 gets (s, ss) of channel c0+k.
-// `ld`: floats per half of a row (= C for the reduction kernels' own partials; the producer's full output width when the
-// sums come fused out of a data-gradient kernel, whose rows cover more columns than this layer has channels)
-__device__ __forceinline__ void reduce_partials4(const float* __restrict__ partial, int nblk, int ld, int c0, double* s, double* ss) {
+__device__ __forceinline__ void reduce_partials4(const float* __restrict__ partial, int nblk, int C, int c0, double* s, double* ss) {
   __shared__ double sh[2][4][4];     // [which][wave][channel]
   double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
   for (int r = threadIdx.x; r < nblk; r += 256) {
-    const f32x4 x = *(const f32x4*)(partial + (long)r * 2 * ld + c0);
-    const f32x4 y = *(const f32x4*)(partial + (long)r * 2 * ld + ld + c0);
+    const f32x4 x = *(const f32x4*)(partial + (long)r * 2 * C + c0);
+    const f32x4 y = *(const f32x4*)(partial + (long)r * 2 * C + C + c0);
 #pragma unroll
     for (int k = 0; k < 4; ++k) { a[k] += (double)x[k]; b[k] += (double)y[k]; }
   }
@@ -137,12 +135,12 @@ __global__ __launch_bounds__(256) void bn_act_apply_kernel(BnCtx p, float* __res
 }
 
 // coef[0][c] = gamma*invstd, coef[1][c] = mean(dz), coef[2][c] = mean(dz*xhat)
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int ld, long P, int C,
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, long P, int C,
                                                               const float* __restrict__ gamma, const float* __restrict__ invstd,
                                                               float* dgamma, float* dbeta, float* coef) {
   const int c0 = blockIdx.x * 4;
   double s, sx;
-  reduce_partials4(partial, nblk, ld, c0, &s, &sx);
+  reduce_partials4(partial, nblk, C, c0, &s, &sx);
   if (threadIdx.x >= 4) return;
   const int c = c0 + threadIdx.x;
   if (dbeta) dbeta[c] = (float)s;
@@ -210,7 +208,7 @@ static int grid_for(long total) {
 }
 
 extern "C" size_t svs_bn_workspace_bytes(int64_t P, int C) {
-  return (size_t)red_blocks(P, C) * 2 * C * sizeof(float) + (size_t)3 * 1024 * sizeof(float);     // partials + coefficient block (at the end)
+  return (size_t)red_blocks(P, C) * 2 * C * sizeof(float) + (size_t)3 * C * sizeof(float);
 }
 
 extern "C" int svs_bn_stats(const float* raw, int64_t ldr, int64_t P, int C, void* ws, size_t ws_bytes, hipStream_t stream) {
@@ -255,6 +253,10 @@ extern "C" int svs_bn_act_apply(const float* raw, int64_t ldr, int64_t P, int C,
   return SVS_OK;
 }
 
+int svs_bn_bwd_run(const float* dy, long lddy, const float* raw, long ldr, long P, int C, long pixels_per_sample,
+                   const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, float slope,
+                   const float* drop, float* d_raw, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes,
+                   hipStream_t stream, float* dbias_partial, SvsSumJobs* defer);
 __global__ void channel_sum_finalize_kernel(const float* __restrict__ partial, int nblk, int C, float* out);
 
 extern "C" int svs_bn_bwd(const float* dy, int64_t lddy, const float* raw, int64_t ldr, int64_t P, int C,
@@ -268,28 +270,21 @@ extern "C" int svs_bn_bwd(const float* dy, int64_t lddy, const float* raw, int64
 int svs_bn_bwd_run(const float* dy, long lddy, const float* raw, long ldr, long P, int C, long pixels_per_sample,
                    const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, float slope,
                    const float* drop, float* d_raw, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes,
-                   hipStream_t stream, float* dbias_partial, SvsSumJobs* defer, const float* pre_partial, int pre_rows, int pre_ld) {
+                   hipStream_t stream, float* dbias_partial, SvsSumJobs* defer) {
   int rc = check_bn("svs_bn_bwd", raw, ldr, P, C);
   if (rc) return rc;
   SVS_REQUIRE(dy && d_raw && lddy >= C && lddy % 4 == 0 && svs_aligned16(dy) && svs_aligned16(d_raw), "svs_bn_bwd: bad gradient view");
   if (!ws || ws_bytes < svs_bn_workspace_bytes(P, C)) { svs_set_error("svs_bn_bwd: workspace too small"); return SVS_ERR_WORKSPACE; }
   const int nb = red_blocks(P, C);
   float* partial = (float*)ws;
-  // the 3*C coefficients live at the END of the workspace: fused partials handed in by the upstream kernel may occupy any
-  // amount of its front
-  float* coef = (float*)((char*)ws + ws_bytes) - 3 * 1024;
+  float* coef = partial + (size_t)nb * 2 * C;
   BnCtx p{}; p.raw = raw; p.ldr = ldr; p.P = P; p.C = C; p.pps = pixels_per_sample;
   p.gamma = gamma; p.beta = beta; p.mean = save_mean; p.invstd = save_invstd; p.slope = slope; p.drop = drop;
   p.dy = dy; p.lddy = lddy;
-  if (pre_partial && pre_rows > 0) {
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C / 4), dim3(256), 0, stream, pre_partial, pre_rows, pre_ld, (long)P, C,
-                       gamma, save_invstd, dgamma, dbeta, coef);
-  } else {
-    hipLaunchKernelGGL(channel_reduce_kernel<1>, dim3(nb), dim3(256), 0, stream, p, partial, (P + nb - 1) / nb);
-    SVS_CHECK_LAUNCH("bn_bwd_reduce");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C / 4), dim3(256), 0, stream, (const float*)partial, nb, C, (long)P, C,
-                       gamma, save_invstd, dgamma, dbeta, coef);
-  }
+  hipLaunchKernelGGL(channel_reduce_kernel<1>, dim3(nb), dim3(256), 0, stream, p, partial, (P + nb - 1) / nb);
+  SVS_CHECK_LAUNCH("bn_bwd_reduce");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C / 4), dim3(256), 0, stream, (const float*)partial, nb, (long)P, C,
+                     gamma, save_invstd, dgamma, dbeta, coef);
   SVS_CHECK_LAUNCH("bn_bwd_finalize");
   // the apply pass reuses the partial buffer of the reduce pass (already consumed by the finalize kernel) unless the
   // caller keeps the bias-gradient partials for a deferred, batched final pass

@@ -21,7 +21,7 @@
 #include <stdlib.h>
 
 #include <type_traits>
-#include "internal.h"
+#include "common.h"
 
 enum { MODE_GATHER = 0, MODE_PARITY = 1 };
 
@@ -42,32 +42,7 @@ struct ConvGemmArgs {
   int cpt_shift;                  // log2(C / 16) when that is a power of two, else -1
   float* stats;                   // non-split kernels: BatchNorm partials of the output, [row][2][N] (row = class * mtiles + mtile
                                   // for the GEMM, = block for the window kernel); null = off
-  int stat_mode;                  // 0: sum v, sum v^2 (forward statistics); 1: BatchNorm-backward sums of `bs` (columns < bs.C)
-  SvsBnBwdStat bs;
 };
-
-// The two per-column sums of one output element for the fused statistics: forward (v, v^2), or the BatchNorm-backward pair
-// (dz, dz * xhat) of the layer whose final dy this element is (SvsBnBwdStat).  `b` = sample index of the pixel (dropout).
-struct BwdCol { float mean, k, beta, inv; };
-// (everything by VALUE: a reference to a member of the by-value kernel argument makes the compiler keep a copy of the whole
-// argument struct in scratch memory -- 400 bytes per lane and a 2-4x slower kernel, measured)
-__device__ __forceinline__ BwdCol bwd_col(const float* mean, const float* invstd, const float* gamma, const float* beta, int C, int n) {
-  BwdCol c{0.f, 0.f, 0.f, 0.f};
-  if (n < C) { c.mean = mean[n]; c.inv = invstd[n]; c.k = gamma[n] * c.inv; c.beta = beta[n]; }
-  return c;
-}
-__device__ __forceinline__ void bwd_sums(const float* raw, long ldr, const float* drop, int C, float slope, BwdCol c, float v, long opix,
-                                         long b, int n, float& s0, float& s1) {
-  if (n >= C) return;
-  const float xm = raw[opix * ldr + n] - c.mean;
-  float dz = drop ? v * drop[b * C + n] : v;
-  dz = (xm * c.k + c.beta) > 0.f ? dz : dz * slope;
-  s0 += dz;
-  s1 += dz * (xm * c.inv);
-}
-#define SVS_BWD_COL(P_, N_) bwd_col((P_).bs.mean, (P_).bs.invstd, (P_).bs.gamma, (P_).bs.beta, (P_).bs.C, N_)
-#define SVS_BWD_SUMS(P_, COL_, V_, OPIX_, B_, N_, S0_, S1_) \
-  bwd_sums((P_).bs.raw, (P_).bs.ldr, (P_).bs.drop, (P_).bs.C, (P_).bs.slope, COL_, V_, OPIX_, B_, N_, S0_, S1_)
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 3); }
 
@@ -285,34 +260,27 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs p) {
 #pragma unroll
   for (int j = 0; j < TN; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
   float* const slab = split ? p.slab + (long)blockIdx.y * ((long)p.B * p.Ho * p.Wo) * p.N : nullptr;
-  const bool bwd_stats = p.stats && !split && p.stat_mode == 1;
-  BwdCol bcol[TN];
-#pragma unroll
-  for (int j = 0; j < TN; ++j) bcol[j] = bwd_stats ? SVS_BWD_COL(p, n0 + wn * (TN * 16) + j * 16 + lrow) : BwdCol{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const long m = m0 + wm * (TM * 16) + i * 16 + q * 4 + r;
       if (m >= M) continue;
-      long opix, bsample = 0;
+      long opix;
       if (SKIP) {
         const unsigned pos = (unsigned)m / (unsigned)p.B;
         const long b = (long)((unsigned)m - pos * (unsigned)p.B);
         const int wq = (int)(pos / (unsigned)Ha);
         const int hq = (int)(pos - (unsigned)wq * (unsigned)Ha);
         opix = (MODE == MODE_GATHER) ? (b * p.Ho + hq) * p.Wo + wq : (b * p.Ho + 2 * hq + ph) * p.Wo + 2 * wq + pw;
-        bsample = b;
       } else if (MODE == MODE_GATHER) {
         opix = m;
-        if (bwd_stats && p.bs.drop) bsample = (long)((unsigned)m / (unsigned)(p.Ho * p.Wo));
       } else {
         const int wq = (int)(m % Wa);
         const long tmp = m / Wa;
         const int hq = (int)(tmp % Ha);
         const long b = tmp / Ha;
         opix = (b * p.Ho + 2 * hq + ph) * p.Wo + 2 * wq + pw;
-        bsample = b;
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
@@ -329,8 +297,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs p) {
           float* dst = p.y + opix * p.ldy + n;
           if (p.accumulate) v += *dst;
           *dst = v;
-          if (bwd_stats) SVS_BWD_SUMS(p, bcol[j], v, opix, bsample, n, ssum[j], ssq[j]);
-          else { ssum[j] += v; ssq[j] += v * v; }
+          ssum[j] += v;
+          ssq[j] += v * v;
         }
       }
     }
@@ -603,14 +571,10 @@ __global__ __launch_bounds__(256) void parity_window_kernel(ConvGemmArgs p) {
 #pragma unroll
   for (int j = 0; j < TN; ++j) { wst.s[j] = 0.f; wst.q[j] = 0.f; }
   // rows q*4 + r of row tile i = anchor (th0 + 2*wave + i, tw0 + q*4 + r); column lrow (+16j) = output channel
-  const bool bwd_stats = p.stats && p.stat_mode == 1;
-  // (always_inline: called four times in the single-phase path; left to the inliner's size heuristic the closure and the
-  // accumulators it references went to scratch memory once the body grew)
-  auto store_class = [&](int par, const f32x4 (&acc)[TM][TN]) __attribute__((always_inline)) -> ColStat {
+  auto store_class = [&](int par, const f32x4 (&acc)[TM][TN]) -> ColStat {
     ColStat cs;
-    BwdCol bcol[TN];                          // (local to the lambda: captured by reference it would live in scratch)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) { cs.s[j] = 0.f; cs.q[j] = 0.f; bcol[j] = bwd_stats ? SVS_BWD_COL(p, j * 16 + lrow) : BwdCol{0.f, 0.f, 0.f, 0.f}; }
+    for (int j = 0; j < TN; ++j) { cs.s[j] = 0.f; cs.q[j] = 0.f; }
     const int ph = par >> 1, pw = par & 1;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -635,8 +599,8 @@ __global__ __launch_bounds__(256) void parity_window_kernel(ConvGemmArgs p) {
           float* dst = p.y + opix * p.ldy + n;
           if (p.accumulate) v += *dst;
           *dst = v;
-          if (bwd_stats) SVS_BWD_SUMS(p, bcol[j], v, opix, b, n, cs.s[j], cs.q[j]);
-          else { cs.s[j] += v; cs.q[j] += v * v; }
+          cs.s[j] += v;
+          cs.q[j] += v * v;
         }
       }
     }
@@ -713,8 +677,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
                                                               const float* __restrict__ bias,
                                                               const float* __restrict__ scale,
                                                               const float* __restrict__ shift, float slope,
-                                                              float* y, long ldy, int accumulate, float* __restrict__ stats,
-                                                              int stat_mode, SvsBnBwdStat bs) {
+                                                              float* y, long ldy, int accumulate, float* __restrict__ stats) {
   __shared__ f32x4 red[2][256];
   const long total4 = P * N / 4;
   const long stride = P * N;
@@ -738,23 +701,8 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
       s[k] = v;
     }
     *(f32x4*)dst = s;
-    if (stats && stat_mode == 1) {            // BatchNorm-backward sums of the layer whose final dy this is (columns < bs.C)
-      if (n < bs.C) {
-        const f32x4 mean4 = *(const f32x4*)(bs.mean + n), inv4 = *(const f32x4*)(bs.invstd + n);
-        const f32x4 k4 = *(const f32x4*)(bs.gamma + n) * inv4, beta4 = *(const f32x4*)(bs.beta + n);
-        const f32x4 xm = *(const f32x4*)(bs.raw + pix * bs.ldr + n) - mean4;
-        f32x4 dz = s;
-        if (bs.drop) dz *= *(const f32x4*)(bs.drop + (pix / bs.pps) * bs.C + n);
-        const f32x4 z = xm * k4 + beta4;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) dz[k] = z[k] > 0.f ? dz[k] : dz[k] * bs.slope;
-        s0 += dz;
-        s1 += dz * (xm * inv4);
-      }
-    } else {
-      s0 += s;
-      s1 += s * s;
-    }
+    s0 += s;
+    s1 += s * s;
   }
   if (!stats) return;
   const int G = N >> 2, PL = 256 / G, t = threadIdx.x;
@@ -889,7 +837,7 @@ static int use_tap_skip(int mode, int B, int C, int Wo, int N, int cfg) {
 int svs_conv_gemm_run(int mode, const float* x, long ldx, int B, int H, int W, int C, const float* wp,
                       const float* bias, const float* scale, const float* shift, float slope, float* y, long ldy,
                       int Ho, int Wo, int N, int accumulate, void* ws, size_t ws_bytes, hipStream_t stream,
-                      const char* who, float* stats, int stats_cap, int* stats_nblk, const SvsBnBwdStat* bwd) {   // stats_cap: capacity of `stats` in floats
+                      const char* who, float* stats, int stats_cap, int* stats_nblk) {   // stats_cap: capacity of `stats` in floats
   if (stats_nblk) *stats_nblk = 0;
   int rc = check_gemm_args(who, x, ldx, B, H, W, C, wp, y, ldy, Ho, Wo, N);
   if (rc) return rc;
@@ -941,10 +889,7 @@ int svs_conv_gemm_run(int mode, const float* x, long ldx, int B, int H, int W, i
     else if (N == 32 && mode == MODE_PARITY && C >= 128) direct = 1;
   }
   if (svs_tune_on(SVS_TUNE_CONV_DIRECT)) { const int f = (int)svs_tune(SVS_TUNE_CONV_DIRECT); if (f == 0 || (N <= 32 && Mmax >= 16384)) direct = f; }  // sweeps
-  // forward statistics describe a freshly written output; the backward sums (bwd) are taken of the FINAL values, i.e. also
-  // after an accumulate (the skip gradient)
-  const bool want_stats = stats && stats_nblk && !scale && (bwd || !accumulate);
-  if (bwd) { a.stat_mode = 1; a.bs = *bwd; SVS_REQUIRE(bwd->C % 4 == 0 && bwd->C <= N, "%s: bad fused BatchNorm-backward request", who); }
+  const bool want_stats = stats && stats_nblk && !scale && !accumulate;
   if (window) {
     a.ksplit = 1; a.slab = nullptr;
     dim3 grid((unsigned)((long)B * ((H + 7) / 8) * ((W + 15) / 16)));
@@ -987,11 +932,11 @@ int svs_conv_gemm_run(int mode, const float* x, long ldx, int B, int H, int W, i
     int grid = (int)((total4 + 255) / 256);
     if (grid > 2048) grid = 2048;
     // fused BatchNorm statistics: stats[grid][2][N] must fit the caller's buffer (stats_cap rows)
-    const bool fuse = stats && stats_nblk && stats_cap >= 2 * N && N % 4 == 0 && N <= 1024 && 256 % (N / 4) == 0 && !scale && (bwd || !accumulate);
+    const bool fuse = stats && stats_nblk && stats_cap >= 2 * N && N % 4 == 0 && N <= 1024 && 256 % (N / 4) == 0 && !scale && !accumulate;
     if (fuse && grid > 512) grid = 512;
     if (fuse && (long)grid * 2 * N > stats_cap) grid = stats_cap / (2 * N);
     hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(grid), dim3(256), 0, stream, a.slab, pl.ksplit, P, N, bias, scale,
-                       shift, slope, y, ldy, accumulate, fuse ? stats : nullptr, a.stat_mode, a.bs);
+                       shift, slope, y, ldy, accumulate, fuse ? stats : nullptr);
     SVS_CHECK_LAUNCH("splitk_epilogue");
     if (fuse) *stats_nblk = grid;
   }

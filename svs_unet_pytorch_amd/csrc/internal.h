@@ -4,20 +4,10 @@
 
 enum { SVS_MODE_GATHER = 0, SVS_MODE_PARITY = 1 };
 
-// BatchNorm-backward sums fused into the kernel that produces the final dy of a BatchNorm layer (the data-gradient kernel
-// upstream of it): per output element v = dy[pix][n] (n < C), dz = v * drop * act'(z), z = (raw - mean) * gamma * invstd +
-// beta; the partial rows then hold sum(dz), sum(dz * xhat) instead of sum(v), sum(v^2) (same row layout).
-struct SvsBnBwdStat {
-  const float* raw; long ldr;                 // pre-BatchNorm output of the layer, (P, C) view
-  const float* mean; const float* invstd; const float* gamma; const float* beta;
-  float slope; const float* drop; long pps;   // drop: (B, C) keep-mask or null; pps = pixels per sample
-  int C;                                      // channels of the BatchNorm layer = columns [0, C) of the producer's output
-};
 int svs_conv_gemm_run(int mode, const float* x, long ldx, int B, int H, int W, int C, const float* wp,
                       const float* bias, const float* scale, const float* shift, float slope, float* y, long ldy,
                       int Ho, int Wo, int N, int accumulate, void* ws, size_t ws_bytes, hipStream_t stream,
-                      const char* who, float* stats = nullptr, int stats_cap = 0, int* stats_nblk = nullptr,
-                      const SvsBnBwdStat* bwd = nullptr);
+                      const char* who, float* stats = nullptr, int stats_cap = 0, int* stats_nblk = nullptr);
 // stats / stats_cap / stats_nblk: the kernel that writes the output (split-K epilogue, GEMM epilogue or window kernel) also
 // writes svs_bn_stats-style partials of it into stats[rows][2][N] (stats_cap = capacity in floats) and reports the number
 // of rows (0: not produced, e.g. the LDS-free direct kernel).
@@ -34,8 +24,7 @@ size_t svs_wgrad_gemm_workspace(int B, int Hs, int Ws, int Cs, int Cl);
 
 int svs_conv_c1_run(const float* x, int B, int H, int W, const float* w, const float* bias, const float* scale,
                     const float* shift, float slope, float* y, long ldy, int N, int accumulate, hipStream_t stream,
-                    const char* who, long half = 0, float* stats = nullptr, int stats_cap = 0, int* stats_nblk = nullptr,
-                    const SvsBnBwdStat* bwd = nullptr);
+                    const char* who, long half = 0);
 int svs_deconv_to1_run(const float* x, long ldx, int B, int H, int W, int C, const float* w, const float* bias,
                        float* y, int Ho, int Wo, int apply_sigmoid, hipStream_t stream, const char* who, long half = 0);
 int svs_wgrad_c1_run(const float* s, long lds, int B, int Hs, int Ws, int Cs, const float* l, int Hl, int Wl,
@@ -58,10 +47,7 @@ int svs_pack_all_run(SvsPackJobs& jobs, hipStream_t stream);
 int svs_bn_bwd_run(const float* dy, long lddy, const float* raw, long ldr, long P, int C, long pixels_per_sample,
                    const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, float slope,
                    const float* drop, float* d_raw, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes,
-                   hipStream_t stream, float* dbias_partial = nullptr, SvsSumJobs* defer = nullptr,
-                   const float* pre_partial = nullptr, int pre_rows = 0, int pre_ld = 0);
-// pre_partial / pre_rows / pre_ld: the reduction pass is skipped -- the sums were left by the upstream data-gradient kernel as
-// pre_rows rows of [sum dz : pre_ld floats | sum dz*xhat : pre_ld floats] (columns [0, C) of each half are this layer's).
+                   hipStream_t stream, float* dbias_partial = nullptr, SvsSumJobs* defer = nullptr);
 // dbias_partial + defer: the per-block sums of d_raw go to dbias_partial (svs_bn_partial_floats(P, C) floats, must
 // stay untouched until the deferred pass) and the final reduction into dbias is appended to *defer instead of being
 // launched -- the caller runs svs_channel_sum_finalize_multi_run once for all layers.

@@ -36,7 +36,7 @@ extern "C" const char* svs_last_error_string(void) { return g_err; }
 // ---------------------------------------------------------------------------------------------
 static const char* const TUNE_NAMES[SVS_TUNE_COUNT] = {
     "CONV_CFG", "CONV_KSPLIT", "CONV_WINDOW", "CONV_SKIP", "CONV_KORDER", "CONV_DIRECT", "SKIP_REDUCE", "WGRAD_CFG",
-    "WGRAD_KSPLIT", "WGRAD_SKIP", "WGRAD_WINDOW", "WGRAD_C1_VALU", "SIDE_PRIORITY", "TRAIN_UNFUSED", "TRAIN_ONE_STREAM", "BWD_STATS"};
+    "WGRAD_KSPLIT", "WGRAD_SKIP", "WGRAD_WINDOW", "WGRAD_C1_VALU", "SIDE_PRIORITY", "TRAIN_UNFUSED", "TRAIN_ONE_STREAM"};
 static long g_tune[SVS_TUNE_COUNT];
 static std::once_flag g_tune_once;
 static void tune_load_env() {
@@ -356,8 +356,7 @@ struct TrainWs {
   float* scratch2; size_t scratch2_bytes;     // split-K slabs of the weight-gradient GEMMs (side stream)
   size_t total;
 };
-#define SVS_FUSED_STATS_ROWS 4096         // rows (of 2 x 512 floats) of fused BatchNorm partials that fit bnws (forward: split-K epilogue
-                                          // rows; backward: one row per M-tile of the upstream data-gradient kernel)
+#define SVS_FUSED_STATS_ROWS 512          // rows of BatchNorm partials the split-K epilogue may write into bnws
 static TrainWs train_layout(const Geo& g, void* ws) {
   TrainWs t{};
   Arena a{(char*)ws, 0};
@@ -604,26 +603,6 @@ static int train_backward_impl(const ParamView& v, float* grads, const float* mi
     }
     return SVS_OK;
   };
-  long drop_off[5];
-  { long o = 0; for (int j = 0; j < 5; ++j) { drop_off[j] = o; o += (long)B * DEC_N[j]; } }
-  // Every data-gradient kernel also leaves the BatchNorm-backward sums of the layer whose dy it completes (SvsBnBwdStat) in
-  // bnws, so that layer's svs_bn_bwd_run starts at the finalize step: pre_rows > 0 says the sums are there.
-  // OFF by default (svs_tuning_set("BWD_STATS", 1) turns it on): in a same-device A/B at B = 64 the fused form is 67 us per
-  // step SLOWER (3.777 vs 3.709 ms) although it removes 9 launches and a full read of (dy, raw) per layer -- the epilogue's
-  // per-element raw / mask loads are 64-byte pieces on the critical path of the main stream, while the stand-alone reduction
-  // streams float4s and overlaps the weight-gradient GEMMs of the side stream.
-  const int bwd_cap = (unfused || svs_tune(SVS_TUNE_BWD_STATS) != 1) ? 0 : (int)(t.bnws_bytes / sizeof(float)) - 3 * 1024;      // (the coefficient block is at the end)
-  int pre_rows = 0, pre_ld = 0;
-  auto bwd_of_dec = [&](int j) {             // decoder j's BatchNorm (layer 6 + j), dy = first half of dcat[5 - j]
-    const int lout = 5 - j, l = 6 + j;
-    return SvsBnBwdStat{t.raw_d[j], (long)DEC_N[j], t.mean[l], t.invstd[l], v.gamma[l], v.beta[l], 0.f,
-                        drop ? drop + drop_off[j] : nullptr, (long)g.h[lout] * g.w[lout], DEC_N[j]};
-  };
-  auto bwd_of_enc = [&](int k) {             // encoder k's BatchNorm (layer k - 1), dy = skip half of dcat[k] (dc6 for k = 6)
-    const int l = k - 1;
-    return SvsBnBwdStat{t.raw_e[k], (long)CH[k], t.mean[l], t.invstd[l], v.gamma[l], v.beta[l], LEAKY, nullptr,
-                        (long)g.h[k] * g.w[k], CH[k]};
-  };
   if (parts & 1) {
   // deconv6 (model.py:109,198): dw, db, dx -> dcat[1]
   const long half1 = g.P[1] * 16;     // level 1 is planar (cat_half)
@@ -632,13 +611,11 @@ static int train_backward_impl(const ParamView& v, float* grads, const float* mi
                              "deconv6 bwd_weight", half1))) return rc;
   if ((rc = svs_sum_run(t.d_logit, g.P[0], G(45), wscratch, wscratch_bytes, wstream))) return rc;      // deconv6 bias gradient
   if ((rc = forked())) return rc;
-  {
-    const SvsBnBwdStat bs = bwd_of_dec(4);
-    if ((rc = svs_conv_c1_run(t.d_logit, B, g.h[0], g.w[0], v.w[11], nullptr, nullptr, nullptr, 0.f, t.dcat[1], 16, 32, 0, stream,
-                              "deconv6 bwd_data", half1, bwd_cap > 0 ? t.bnws : nullptr, bwd_cap, &pre_rows, &bs))) return rc;
-    pre_ld = 16;
-  }
+  if ((rc = svs_conv_c1_run(t.d_logit, B, g.h[0], g.w[0], v.w[11], nullptr, nullptr, nullptr, 0.f, t.dcat[1], 16, 32, 0, stream,
+                            "deconv6 bwd_data", half1))) return rc;
   // decoders 5..1
+  long drop_off[5];
+  { long o = 0; for (int j = 0; j < 5; ++j) { drop_off[j] = o; o += (long)B * DEC_N[j]; } }
   for (int j = 4; j >= 0; --j) {
     const int lin = 6 - j, lout = 5 - j, l = 6 + j, N = DEC_N[j], C = DEC_C[j];
     const float* x = (j == 0) ? t.c6 : t.cat[lin];
@@ -646,25 +623,15 @@ static int train_backward_impl(const ParamView& v, float* grads, const float* mi
     float* const d_raw = layer_draw(l);
     rc = svs_bn_bwd_run(dyv.p, dyv.ld, t.raw_d[j], N, g.P[lout], N, (long)g.h[lout] * g.w[lout], v.gamma[l], v.beta[l],
                         t.mean[l], t.invstd[l], 0.f, drop ? drop + drop_off[j] : nullptr, d_raw, G(24 + 4 * j + 2), G(24 + 4 * j + 3),
-                        G(24 + 4 * j + 1), t.bnws, t.bnws_bytes, stream, unfused ? nullptr : t.dbias_part[l], &sums,   // + bias gradient (sum of d_raw)
-                        pre_rows > 0 ? t.bnws : nullptr, pre_rows, pre_ld);
+                        G(24 + 4 * j + 1), t.bnws, t.bnws_bytes, stream, unfused ? nullptr : t.dbias_part[l], &sums);   // + bias gradient (sum of d_raw)
     if (rc) return rc;
-    pre_rows = 0;
     if ((rc = fork())) return rc;
     if ((rc = svs_dec_block_bwd_weight(x, C, B, g.h[lin], g.w[lin], C, d_raw, N, g.h[lout], g.w[lout], N, G(24 + 4 * j), nullptr,
                                        wscratch, wscratch_bytes, wstream))) return rc;
     if ((rc = forked())) return rc;
     float* dx = (j == 0) ? t.dc6 : t.dcat[lin];
-    // this data gradient completes the dy of decoder j-1's BatchNorm (first half of dcat[lin]), or of conv6's (dc6)
-    // (not across the two places where a split pass may be cut -- decoder | conv6 block | conv5..1: nothing but device
-    // buffers survives between the calls, and the split pass must reproduce the fused one bit for bit, so conv6's and conv5's
-    // BatchNorm always run their own reduction)
-    const SvsBnBwdStat bs = (j == 0) ? bwd_of_enc(6) : bwd_of_dec(j - 1);
-    const bool fuse_next = bwd_cap > 0 && j > 0;
-    if ((rc = svs_conv_gemm_run(SVS_MODE_GATHER, d_raw, N, B, g.h[lout], g.w[lout], N, t.wbwd[l], nullptr, nullptr, nullptr, 0.f, dx, C,
-                                g.h[lin], g.w[lin], C, 0, t.scratch, t.scratch_bytes, stream, "svs_dec_block_bwd_data",
-                                fuse_next ? t.bnws : nullptr, bwd_cap, &pre_rows, &bs))) return rc;
-    pre_ld = C;
+    if ((rc = svs_dec_block_bwd_data(d_raw, N, B, g.h[lout], g.w[lout], N, t.wbwd[l], dx, C, g.h[lin], g.w[lin], C, 0,
+                                     t.scratch, t.scratch_bytes, stream))) return rc;
   }
   if ((rc = svs_channel_sum_finalize_multi_run(sums, stream))) return rc;    // the five decoder bias gradients
   sums.njobs = 0;
@@ -679,9 +646,8 @@ static int train_backward_impl(const ParamView& v, float* grads, const float* mi
     float* const d_raw = layer_draw(l);
     rc = svs_bn_bwd_run(dy, lddy, t.raw_e[k], N, g.P[k], N, (long)g.h[k] * g.w[k], v.gamma[l], v.beta[l], t.mean[l], t.invstd[l],
                         LEAKY, nullptr, d_raw, G(4 * l + 2), G(4 * l + 3), G(4 * l + 1), t.bnws, t.bnws_bytes, stream,
-                        unfused ? nullptr : t.dbias_part[l], &sums, pre_rows > 0 ? t.bnws : nullptr, pre_rows, pre_ld);
+                        unfused ? nullptr : t.dbias_part[l], &sums);
     if (rc) return rc;
-    pre_rows = 0;
     const View xi = (k == 1) ? View{const_cast<float*>(mix), 1} : cat_half(t.cat, g, k - 1, 1);
     const float* x = xi.p; const long ldx = xi.ld;
     if ((rc = fork())) return rc;
@@ -690,14 +656,9 @@ static int train_backward_impl(const ParamView& v, float* grads, const float* mi
     if ((rc = forked())) return rc;
     if (k >= 2) {
       // gradient of the skip half of cat[k-1]: add to what decoder (7-k)'s bwd_data left there
-      // (this accumulate completes the dy of encoder k-1's BatchNorm: its backward sums are taken here)
       const View dxs = cat_half(t.dcat, g, k - 1, 1);
-      const SvsBnBwdStat bs = bwd_of_enc(k - 1);
-      const bool fuse_next = bwd_cap > 0 && k < 6;
-      if ((rc = svs_conv_gemm_run(SVS_MODE_PARITY, d_raw, N, B, g.h[k], g.w[k], N, t.wbwd[l], nullptr, nullptr, nullptr, 0.f, dxs.p, dxs.ld,
-                                  g.h[k - 1], g.w[k - 1], C, 1, t.scratch, t.scratch_bytes, stream, "svs_enc_block_bwd_data",
-                                  fuse_next ? t.bnws : nullptr, bwd_cap, &pre_rows, &bs))) return rc;
-      pre_ld = C;
+      if ((rc = svs_enc_block_bwd_data(d_raw, N, B, g.h[k], g.w[k], N, t.wbwd[l], dxs.p, dxs.ld, g.h[k - 1], g.w[k - 1], C, 1,
+                                       t.scratch, t.scratch_bytes, stream))) return rc;
     }
   }
   if ((rc = svs_channel_sum_finalize_multi_run(sums, stream))) return rc;    // the encoder bias gradients of this call

@@ -15,10 +15,7 @@ struct C1Args {
   const float* bias; const float* scale; const float* shift; float slope;
   float* y; long ldy; int Ho, Wo; int accumulate;
   long half;                              // floats between channel COUT/2-1 and COUT/2 of a pixel minus ... see chan_off()
-  float* stats; SvsBnBwdStat bs;          // optional: BatchNorm-backward sums of columns [0, bs.C <= 16) of what is written (rows [2][16])
 };
-
-struct BwdCol1 { float mean, k, beta, inv; };
 
 // Address of channel group `sub` (4 channels) of pixel `pix` in a view whose two channel halves may live in
 // different places ("planar" level-1 buffers: the decoder half and the skip half of the 32-channel level-1
@@ -89,52 +86,17 @@ __global__ __launch_bounds__(256) void conv_c1_kernel(C1Args p) {
       *(f32x4*)dst = v;
     }
   }
-  if (p.stats) {
-    // these outputs are the final dy of a BatchNorm layer (deconv6's data gradient -> deconv5_BAD): leave its backward sums
-    // (sum dz, sum dz*xhat per channel) for this block's 256 pixels, so that the layer needs no reduction pass of its own
-    __shared__ float red[2][16][17];
-    const int c = threadIdx.x & 15, grp = threadIdx.x >> 4;
-    float s0 = 0.f, s1 = 0.f;
-    if (c < p.bs.C) {
-      const float mean = p.bs.mean[c], inv = p.bs.invstd[c], k = p.bs.gamma[c] * inv, beta = p.bs.beta[c];
-      const long pps = (long)p.Ho * p.Wo;
-      for (int i = 0; i < 16; ++i) {
-        const int pp = grp * 16 + i;
-        const long px = pix0 + pp;
-        if (px >= P) break;
-        const float xm = p.bs.raw[px * p.bs.ldr + c] - mean;
-        float dz = tile[pp * LD + c];
-        if (p.bs.drop) dz *= p.bs.drop[(px / pps) * p.bs.C + c];
-        dz = (xm * k + beta) > 0.f ? dz : dz * p.bs.slope;
-        s0 += dz;
-        s1 += dz * (xm * inv);
-      }
-    }
-    red[0][grp][c] = s0;
-    red[1][grp][c] = s1;
-    __syncthreads();
-    if (threadIdx.x < 32) {
-      const int which = threadIdx.x >> 4, cc = threadIdx.x & 15;
-      float a = 0.f;
-      for (int g2 = 0; g2 < 16; ++g2) a += red[which][g2][cc];
-      p.stats[(long)blockIdx.x * 32 + which * 16 + cc] = a;
-    }
-  }
 }
 
 int svs_conv_c1_run(const float* x, int B, int H, int W, const float* w, const float* bias, const float* scale,
                     const float* shift, float slope, float* y, long ldy, int N, int accumulate, hipStream_t stream,
-                    const char* who, long half, float* stats, int stats_cap, int* stats_nblk, const SvsBnBwdStat* bwd) {
-  if (stats_nblk) *stats_nblk = 0;
+                    const char* who, long half) {
   SVS_REQUIRE(x && w && y, "%s: null pointer", who);
   SVS_REQUIRE(N == 16 || N == 32, "%s: single-channel conv supports N=16/32, got %d", who, N);
   SVS_REQUIRE(ldy >= (half ? N / 2 : N) && ldy % 4 == 0 && svs_aligned16(y), "%s: bad output view", who);
-  C1Args a{x, B, H, W, w, bias, scale, shift, slope, y, ldy, svs_conv_out(H), svs_conv_out(W), accumulate, half, nullptr, {}};
+  C1Args a{x, B, H, W, w, bias, scale, shift, slope, y, ldy, svs_conv_out(H), svs_conv_out(W), accumulate, half};
   const long total = (long)B * a.Ho * a.Wo;
   const int grid = (int)((total + 255) / 256);
-  if (bwd && stats && stats_nblk && !accumulate && !scale && bwd->C <= 16 && (long)grid * 32 <= stats_cap) {
-    a.stats = stats; a.bs = *bwd; *stats_nblk = grid;
-  }
   if (N == 16) hipLaunchKernelGGL(conv_c1_kernel<16>, dim3(grid), dim3(256), 0, stream, a);
   else hipLaunchKernelGGL(conv_c1_kernel<32>, dim3(grid), dim3(256), 0, stream, a);
   SVS_CHECK_LAUNCH("conv_c1");

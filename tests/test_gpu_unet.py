@@ -556,30 +556,3 @@ def test_eval_forward_bf16(report):
         ref = uo.forward(st, torch.from_numpy(x_np[:1]))
     assert report("bf16 eval mask mean |d| vs fp32 CPU oracle", (got[:1] - ref).abs().mean().item(), 1e-2)
 
-
-def test_fused_bn_backward_sums_switch(report, tune):
-    """The opt-in path that takes a BatchNorm layer's backward sums in the epilogue of the upstream data-gradient kernel
-    (svs_tuning_set("BWD_STATS", 1); off by default because it measured slower) against the default path: same loss bit
-    for bit (the forward is untouched), gradients equal up to the summation order of the two reductions."""
-    B = 32
-    mix_np, voc_np = synth.tiles(B, first_tile=3100)
-    mix, voc = torch.from_numpy(mix_np).to(DEV), torch.from_numpy(voc_np).to(DEV)
-    masks = [torch.from_numpy(m) for m in synth.dropout_masks(B, seed=23, step=0)]
-
-    def run():
-        m = make_model(trained_stats=False).train()
-        m.set_dropout_masks(masks)
-        m.optim.zero_grad()
-        loss = m.fwd_bwd(mix, voc, loss_scale=166.66)
-        torch.cuda.synchronize()
-        return loss.item(), _grads_by_name(m)
-
-    loss_a, ga = run()
-    tune("BWD_STATS", 1)
-    loss_b, gb = run()
-    assert loss_a == loss_b
-    for n in ga:
-        if n.endswith(".bias") and n != "deconv6.bias" and "BAD" not in n and ".1." not in n:
-            continue                                           # bias in front of a BatchNorm: rounding noise around 0
-        d = (ga[n] - gb[n]).norm().item() / max(ga[n].norm().item(), 1e-12)
-        assert report(f"fused BN-bwd sums vs default: grad {n}", d, 1e-2)

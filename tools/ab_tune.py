@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Same-device, same-process A/B of one tuning switch on the whole train step (devices differ by several %, so two gpurun
-calls cannot be compared):  python tools/ab_tune.py BWD_STATS 0 [-1] [--batch 64] [--rounds 4] [--steps 30]"""
+calls cannot be compared):  python tools/ab_tune.py TRAIN_ONE_STREAM 1 [-1] [--batch 64] [--rounds 4] [--steps 30]"""
 import argparse
 import os
 import sys
