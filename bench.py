@@ -251,6 +251,26 @@ def eval_record(model, dev, B=16, steps=30, warmup=5):
                             "frac": round(B / ms * 1e3 * FWD_GFLOP_PER_TILE / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4)}
         except Exception as e:                      # the graph path is an optimisation, never a correctness dependency
             out["graph_error"] = str(e)[:200]
+        # the same forward on the bf16 MFMA (BASELINE configs[4]; reported separately: bf16 activations, fp32 accumulation)
+        try:
+            model.eval_precision = "fp32"
+            ref = model(mix)
+            model.eval_precision = "bf16"
+            got = model(mix)
+            for _ in range(warmup):
+                model(mix)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                model(mix)
+            torch.cuda.synchronize()
+            ms = 1e3 * (time.perf_counter() - t0) / steps
+            out["bf16"] = {"ms": round(ms, 4), "tiles_per_s": round(B / ms * 1e3, 1),
+                           "mask_mean_abs_diff_vs_fp32": float((got - ref).abs().mean()), "mask_max_abs_diff_vs_fp32": float((got - ref).abs().max())}
+        except Exception as e:
+            out["bf16_error"] = str(e)[:200]
+        finally:
+            model.eval_precision = "fp32"
     model.train(was)
     out["batch"] = B
     out["roofline_tiles_per_s"] = round(FP32_MFMA_PEAK_TFLOPS * 1e3 / FWD_GFLOP_PER_TILE, 1)

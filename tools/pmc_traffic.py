@@ -5,7 +5,7 @@ pass, MI355X_MICROARCH.md 'rocprofv3 PMC slots') into per-kernel HBM bytes per l
     hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024
 
 FETCH_SIZE is doubled: on gfx950 it reports half the bytes of wide (16 B/lane) streaming reads
-(MI355X_MICROARCH.md 'HBM').  Writes profiles/r01_pmc_traffic.json, which bench.py reads for `roofline.traffic`.
+(MI355X_MICROARCH.md 'HBM').  Writes profiles/r02_pmc_traffic.json, which bench.py reads for `roofline.traffic`.
 
     python tools/pmc_traffic.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> [out.json]
 """
@@ -39,10 +39,12 @@ def main():
         out[k] = {"fetch_size_kb_per_launch": round(f, 1), "write_size_kb_per_launch": round(w, 1),
                   "hbm_bytes_per_launch": int((2 * f + w) * 1024)}
     path = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                                                              "profiles", "r01_pmc_traffic.json")
+                                                              "profiles", "r02_pmc_traffic.json")
+    if len(sys.argv) > 4:
+        out["_commit"] = sys.argv[4]            # the commit the counters were taken at (bench.py quotes it with `traffic`)
     with open(path, "w") as fh:
         json.dump(out, fh, indent=1)
-    for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"])[:12]:
+    for k, v in sorted(((k, v) for k, v in out.items() if isinstance(v, dict)), key=lambda kv: -kv[1]["hbm_bytes_per_launch"])[:12]:
         print(f"{k[:70]:70s} {v['hbm_bytes_per_launch'] / 1e6:9.1f} MB/launch")
 
 
