@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Times every MFMA GEMM call of one training step (forward, backward-data, backward-weight of each
 layer) at a given batch, for every tile configuration / K-split the library can be forced into
-(SVS_CONV_CFG, SVS_CONV_KSPLIT, SVS_WGRAD_KSPLIT: debugging overrides read by the planners).
+(CONV_CFG, CONV_KSPLIT, WGRAD_KSPLIT: planner overrides set through svs_tuning_set).
 Used to derive the planner's tables; writes gpurun_out/gemm_sweep_B<B>.txt.
 
     python tools/gemm_sweep.py [--batch 64] [--quick]
@@ -50,9 +50,12 @@ def main():
     ap.add_argument("--no-conv", action="store_true")
     ap.add_argument("--no-ks", action="store_true", help="skip the K-split sweep of the weight gradients")
     ap.add_argument("--ab", action="store_true", help="A/B an environment switch per call (see --ab-env)")
-    ap.add_argument("--ab-env", default="SVS_CONV_KORDER", help="switch toggled by --ab")
+    ap.add_argument("--ab-env", default="CONV_KORDER", help="switch toggled by --ab")
     ap.add_argument("--ab-vals", default="0,1", help="comma-separated values of the switch")
+    ap.add_argument("--ks", default="1,2,4,8", help="K-splits to try for the conv GEMMs")
+    ap.add_argument("--fwd-only", action="store_true", help="forward calls only (eval)")
     args = ap.parse_args()
+    args.ks_list = tuple(int(t) for t in args.ks.split(","))
     B = args.batch
     L = _lib.lib()
     dev = "cuda"
@@ -75,7 +78,7 @@ def main():
     only = [t for t in args.only.split(",") if t]
     cfgs = [int(t) for t in args.cfgs.split(",") if t]
     for name, mode, (h, w, C), (ho, wo, N) in calls:
-        if args.no_conv or (only and not any(t in name for t in only)):
+        if args.no_conv or (only and not any(t in name for t in only)) or (args.fwd_only and not name.endswith(".fwd")):
             continue
         x = torch.rand((B, h, w, C), device=dev) - 0.5
         wp = (torch.rand(N * C * 25, device=dev) - 0.5) * 0.05
@@ -87,8 +90,8 @@ def main():
         else:
             run = lambda: L.svs_dec_block_fwd(x.data_ptr(), C, B, h, w, C, wp.data_ptr(), None, None, None, 0.0, y.data_ptr(), N, ho, wo, N, 0,
                                               ws.data_ptr(), ws.numel(), _lib.stream_ptr())
-        os.environ.pop("SVS_CONV_CFG", None)
-        os.environ.pop("SVS_CONV_KSPLIT", None)
+        _lib.tuning("CONV_CFG")
+        _lib.tuning("CONV_KSPLIT")
         _lib.check(run(), name)
         base = timeit(run)
         emit(f"{name:18s} {mode:6s} in {h}x{w}x{C} out {ho}x{wo}x{N} {gflop:7.2f} GFLOP  default {base * 1e3:8.1f} us {gflop / base:6.1f} TF")
@@ -96,29 +99,29 @@ def main():
         for cfg, (bm, bn) in CFG.items():
             if N % bn or (cfgs and cfg not in cfgs):
                 continue
-            for ks in ((1, 2, 4, 8) if not args.quick else (1, 4)):
-                os.environ["SVS_CONV_CFG"] = str(cfg)
-                os.environ["SVS_CONV_KSPLIT"] = str(ks)
+            for ks in (args.ks_list if not args.quick else (1, 4)):
+                _lib.tuning("CONV_CFG", cfg)
+                _lib.tuning("CONV_KSPLIT", ks)
                 if run() != 0:
                     continue
                 t = timeit(run)
                 emit(f"    cfg{cfg} {bm:3d}x{bn:3d} ks{ks:<3d} {t * 1e3:8.1f} us {gflop / t:6.1f} TF")
                 if t < best[0]:
                     best = (t, f"cfg{cfg} ks{ks}")
-        os.environ.pop("SVS_CONV_CFG", None)
-        os.environ.pop("SVS_CONV_KSPLIT", None)
+        _lib.tuning("CONV_CFG")
+        _lib.tuning("CONV_KSPLIT")
         if args.ab:
             res = []
             for rnd in range(3):               # interleaved A/B in one process (guide rule 24)
                 for ko in args.ab_vals.split(","):
-                    os.environ[args.ab_env] = ko
+                    _lib.tuning(args.ab_env, int(ko))
                     run()
                     res.append((ko, timeit(run)))
-            os.environ.pop(args.ab_env, None)
+            _lib.tuning(args.ab_env)
             emit(f"    A/B {args.ab_env}: " + "  ".join(f"={v} {min(t for k, t in res if k == v) * 1e3:7.1f} us" for v in args.ab_vals.split(",")))
         emit(f"  -> best {best[1]} {best[0] * 1e3:.1f} us {gflop / best[0]:.1f} TF")
-    os.environ.pop("SVS_CONV_CFG", None)
-    os.environ.pop("SVS_CONV_KSPLIT", None)
+    _lib.tuning("CONV_CFG")
+    _lib.tuning("CONV_KSPLIT")
 
     wg = []
     if args.no_wgrad:
@@ -137,7 +140,7 @@ def main():
         gflop = 2.0 * B * hs * wsz * cs * cl * 25 / 1e9
         run = lambda: L.svs_enc_block_bwd_weight(s.data_ptr(), cs, B, hs, wsz, cs, l.data_ptr(), cl, hl, wl, cl, dw.data_ptr(), None,
                                                  ws.data_ptr(), ws.numel(), _lib.stream_ptr())
-        os.environ.pop("SVS_WGRAD_KSPLIT", None)
+        _lib.tuning("WGRAD_KSPLIT")
         _lib.check(run(), name)
         base = timeit(run)
         emit(f"{name:20s} S {hs}x{wsz}x{cs} L {hl}x{wl}x{cl} {gflop:7.2f} GFLOP  default {base * 1e3:8.1f} us {gflop / base:6.1f} TF")
@@ -145,18 +148,18 @@ def main():
             res = []
             for rnd in range(3):
                 for ko in args.ab_vals.split(","):
-                    os.environ[args.ab_env] = ko
+                    _lib.tuning(args.ab_env, int(ko))
                     run()
                     res.append((ko, timeit(run)))
-            os.environ.pop(args.ab_env, None)
+            _lib.tuning(args.ab_env)
             emit(f"    A/B {args.ab_env}: " + "  ".join(f"={v} {min(t for k, t in res if k == v) * 1e3:7.1f} us" for v in args.ab_vals.split(",")))
         for ks in (() if args.no_ks else (1, 2, 4, 8, 16, 32, 64, 128, 256)):
-            os.environ["SVS_WGRAD_KSPLIT"] = str(ks)
+            _lib.tuning("WGRAD_KSPLIT", ks)
             if run() != 0:
                 continue
             t = timeit(run)
             emit(f"    ks{ks:<4d} {t * 1e3:8.1f} us {gflop / t:6.1f} TF")
-    os.environ.pop("SVS_WGRAD_KSPLIT", None)
+    _lib.tuning("WGRAD_KSPLIT")
     out.close()
 
 
