@@ -36,7 +36,16 @@ def _shard(rank):
     return torch.from_numpy(mix).to("cuda"), torch.from_numpy(voc).to("cuda")
 
 
-def _worker(rank, world, port, out):
+def _extras(rank, full):
+    """keyword arguments of the full objective (train.py:287-296): phase tiles as angles + the MR-STFT weight"""
+    if not full:
+        return {}
+    n = B * 512 * 128
+    ang = lambda seed: torch.from_numpy((synth.uniform(seed + rank, n) * 2 * np.pi - np.pi).astype(np.float32).reshape(B, 1, 512, 128)).to("cuda")
+    return dict(mix_phase=ang(70), voc_phase=ang(80), alpha_mr=0.66)
+
+
+def _worker(rank, world, port, out, full):
     import torch.distributed as dist
     from svs_unet_pytorch_amd.parallel import GradAllReduce, broadcast_parameters
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -49,18 +58,20 @@ def _worker(rank, world, port, out):
         sync = GradAllReduce(model)
         assert sync.overlap and model.rank == rank and model.optim.grad_scale == 0.5
         mix, voc = _shard(rank)
-        losses = [model.train_step(mix, voc, loss_scale=SCALE, grad_sync=sync).item() for _ in range(STEPS)]
+        extra = _extras(rank, full)
+        losses = [model.train_step(mix, voc, loss_scale=SCALE, grad_sync=sync, **extra).item() for _ in range(STEPS)]
         torch.cuda.synchronize()
         out.put((rank, losses, model._flat.cpu().numpy(), model._bn_flat.cpu().numpy()))
     finally:
         dist.destroy_process_group()
 
 
-def test_two_rank_overlapped_step_matches_single_process(report):
+@pytest.mark.parametrize("full", [False, True], ids=["l1", "l1+mrstft"])
+def test_two_rank_overlapped_step_matches_single_process(full, report):
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out, full)) for r in range(2)]
     for p in procs:
         p.start()
     got = {}
@@ -75,6 +86,7 @@ def test_two_rank_overlapped_step_matches_single_process(report):
     # the same two steps in one process: rank r's model sees shard r (its own BatchNorm statistics and dropout stream)
     models = [_fresh_model() for _ in range(2)]
     shards = [_shard(r) for r in range(2)]
+    extras = [_extras(r, full) for r in range(2)]
     for r, m in enumerate(models):
         m.rank = r
         m.optim.grad_scale = 0.5
@@ -82,7 +94,7 @@ def test_two_rank_overlapped_step_matches_single_process(report):
     for _ in range(STEPS):
         for r, m in enumerate(models):
             m.optim.zero_grad()
-            losses[r].append(m.fwd_bwd(*shards[r], loss_scale=SCALE).item())
+            losses[r].append(m.fwd_bwd(*shards[r], loss_scale=SCALE, **extras[r]).item())
         total = models[0]._gflat + models[1]._gflat
         for m in models:
             m._gflat.copy_(total)
@@ -92,4 +104,4 @@ def test_two_rank_overlapped_step_matches_single_process(report):
         assert got[r][0] == losses[r], (got[r][0], losses[r])
         assert np.array_equal(got[r][1], models[r]._flat.cpu().numpy()), f"rank {r} parameters"
         assert np.array_equal(got[r][2], models[r]._bn_flat.cpu().numpy()), f"rank {r} BatchNorm buffers"
-    report("two ranks (gloo) vs single-process emulation: parameters bit-identical", 0.0, 0.0)
+    report(f"two ranks (gloo) vs single-process emulation ({'full objective' if full else 'L1'}): parameters bit-identical", 0.0, 0.0)
