@@ -29,40 +29,41 @@ static const int MR_HOP[MR_NRES] = {120, 240, 50};
 static const int MR_WIN[MR_NRES] = {600, 1200, 240};
 #define MR_EPS 1e-8f
 
-// waves (= independent transforms) per block: the LDS of eight 2048-point buffers would exceed 160 KB
-// (no window table in LDS either -- the window is one v_cos_f32 per sample -- so that 1024-point blocks (8 waves, 78 KB) and
-// 2048-point blocks (3 waves, 69 KB) fit twice per CU)
-template <int N> struct MrCfg { static constexpr int WAVES = (N == 2048) ? 3 : 8; };
-static int mr_waves(int n) { return n == 2048 ? 3 : 8; }
+// 8 waves (= independent transforms) per block at every size: 79 KB of LDS for 1024 points (two blocks per CU), 158 KB for 2048
+// (one block per CU; three waves per block, which fits twice, measured 1.65x slower: 530 vs 321 us for the gradient kernel).
+// No window table in LDS -- the window is one v_cos_f32 per sample.
+template <int N> struct MrCfg {
+  static constexpr int WAVES = 8;
+  static constexpr int WIN = (N == 2048) ? 1200 : (N == 1024) ? 600 : 240;      // = MR_WIN of this n_fft (checked on the host)
+  static constexpr int OFF = (N - WIN) / 2, NJ = (WIN + 63) / 64;
+};
+static int mr_waves(int n) { (void)n; return 8; }
 
 struct MrArgs {
   const float* x; const float* y; int B; long L;     // predicted / target waveforms (B, L)
   int hop, win, F;                                   // this resolution: hop, window length, frames = 1 + L / hop
   float* partial;                                    // [B * gridDim.x][3]
   const float* coef;                                 // [2]: SC and log-magnitude gradient coefficients (device)
-  float* frames;                                     // [B][F][N] windowed frame gradients
+  float* frames;                                     // [B][F][win] windowed frame gradients (the window's support only)
 };
 
-// periodic Hann window of `win` samples centred inside n_fft (torch.stft pads a short window on both sides), sample m;
-// v_cos_f32 takes revolutions (absolute error ~1e-6, far below the loss tolerance)
-template <int N>
-__device__ __forceinline__ float mr_window(int m, int win, float inv_win) {
-  const int j = m - (N - win) / 2;
-  return (j >= 0 && j < win) ? 0.5f - 0.5f * __builtin_amdgcn_cosf((float)j * inv_win) : 0.f;
-}
+// periodic Hann window of `win` samples, centred inside n_fft (torch.stft pads a short window on both sides), sample j of the
+// window; v_cos_f32 takes revolutions (absolute error ~1e-6, far below the loss tolerance)
+__device__ __forceinline__ float mr_window_at(int j, float inv_win) { return 0.5f - 0.5f * __builtin_amdgcn_cosf((float)j * inv_win); }   // 0 <= j < win
 __device__ __forceinline__ long mr_reflect(long p, long L) { return p < 0 ? -p : (p >= L ? 2 * (L - 1) - p : p); }
 
 // frame t of x (real part) and y (imaginary part), windowed, into the wave's buffer
 template <int N>
 __device__ __forceinline__ void mr_fill(float2* buf, const MrArgs& p, int b, int t, int lane) {
-  const float inv_win = 1.0f / (float)p.win;
+  constexpr int WIN = MrCfg<N>::WIN, off = MrCfg<N>::OFF;   // the window covers samples off .. off + win - 1 of the frame: nothing else is read
+  const float inv_win = 1.0f / (float)WIN;
 #pragma unroll 4
   for (int r = 0; r < N / 64; ++r) {
-    const int m = lane + 64 * r;
+    const int m = lane + 64 * r, j = m - off;
     float2 v = float2{0.f, 0.f};
-    if (t < p.F) {
+    if (t < p.F && j >= 0 && j < WIN) {
       const long s = mr_reflect((long)t * p.hop + m - N / 2, p.L);
-      const float w = mr_window<N>(m, p.win, inv_win);
+      const float w = mr_window_at(j, inv_win);
       v = float2{p.x[(long)b * p.L + s] * w, p.y[(long)b * p.L + s] * w};
     }
     buf[fft_pad(m)] = v;
@@ -120,12 +121,12 @@ struct MrFinalArgs {
   const float* partial[MR_NRES]; int nblk[MR_NRES]; double count[MR_NRES];
   float grad_scale; float* loss; float* coef;        // coef: [MR_NRES][2]
 };
-__global__ __launch_bounds__(256) void mr_finalize_kernel(MrFinalArgs a) {
-  __shared__ double sh[MR_NRES][3][4];
+__global__ __launch_bounds__(1024) void mr_finalize_kernel(MrFinalArgs a) {
+  __shared__ double sh[MR_NRES][3][16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int r = 0; r < MR_NRES; ++r) {
     double s[3] = {0.0, 0.0, 0.0};
-    for (int i = tid; i < a.nblk[r]; i += 256)
+    for (int i = tid; i < a.nblk[r]; i += 1024)
       for (int j = 0; j < 3; ++j) s[j] += (double)a.partial[r][(long)i * 3 + j];
     for (int j = 0; j < 3; ++j) {
       for (int o = 32; o > 0; o >>= 1) s[j] += __shfl_xor(s[j], o, 64);
@@ -137,7 +138,10 @@ __global__ __launch_bounds__(256) void mr_finalize_kernel(MrFinalArgs a) {
     double total = 0.0;
     for (int r = 0; r < MR_NRES; ++r) {
       double s[3];
-      for (int j = 0; j < 3; ++j) s[j] = (sh[r][j][0] + sh[r][j][1]) + (sh[r][j][2] + sh[r][j][3]);
+      for (int j = 0; j < 3; ++j) {
+        s[j] = 0.0;
+        for (int w = 0; w < 16; ++w) s[j] += sh[r][j][w];
+      }
       const double nd = sqrt(s[0]), ny = sqrt(s[1]);
       total += (ny > 0.0 ? nd / ny : 0.0) + s[2] / a.count[r];
       // d/d|X| of  ||Y|-|X||_F / ||Y||_F  is  -(|Y|-|X|) / (||Y|-|X||_F ||Y||_F);  of the mean log distance  sign / (count |X|)
@@ -151,7 +155,7 @@ __global__ __launch_bounds__(256) void mr_finalize_kernel(MrFinalArgs a) {
 template <int N>
 __global__ __launch_bounds__(64 * MrCfg<N>::WAVES) void mr_grad_kernel(MrArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int BUF = FftSize<N>::BUF, TW = FftSize<N>::TW, NR = N / 128 + 1, WV = MrCfg<N>::WAVES;
+  constexpr int BUF = FftSize<N>::BUF, NR = N / 128 + 1, WV = MrCfg<N>::WAVES;
   float2* const fbuf = (float2*)smem;
   float2* const tw = fbuf + WV * BUF;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -197,29 +201,36 @@ __global__ __launch_bounds__(64 * MrCfg<N>::WAVES) void mr_grad_kernel(MrArgs p)
     if (k > 0 && k < N / 2) buf[fft_pad(N - k)] = float2{a.x + c.y, -(c.x - a.y)};
   }
   fft_wave<N>(buf, tw, lane);
-  float* const fa = p.frames + ((long)b * p.F + ta) * N;
-#pragma unroll 4
-  for (int r = 0; r < N / 64; ++r) {
-    const int m = lane + 64 * r;
-    const float2 z = buf[fft_pad(m)];
-    const float w = mr_window<N>(m, p.win, 1.0f / (float)p.win);
-    fa[m] = z.x * w;
-    if (ta + 1 < p.F) fa[N + m] = -z.y * w;
+  constexpr int WIN = MrCfg<N>::WIN, off = MrCfg<N>::OFF;
+  float* const fa = p.frames + ((long)b * p.F + ta) * WIN;
+  const float inv_win = 1.0f / (float)WIN;
+  const bool second = ta + 1 < p.F;
+#pragma unroll 5
+  for (int r = 0; r < MrCfg<N>::NJ; ++r) {           // the window is zero outside its support: only `win` of the N samples exist
+    const int j = lane + 64 * r;
+    if (j >= WIN) break;
+    const float2 z = buf[fft_pad(j + off)];
+    const float w = mr_window_at(j, inv_win);
+    fa[j] = z.x * w;
+    if (second) fa[WIN + j] = -z.y * w;
   }
 }
 
 struct MrOlaArgs {
-  const float* frames[MR_NRES]; int n[MR_NRES], hop[MR_NRES], F[MR_NRES];
+  const float* frames[MR_NRES]; int n[MR_NRES], hop[MR_NRES], F[MR_NRES], win[MR_NRES];
   int B; long L; float* d_x;
 };
-// contributions of padded position q (= p + N/2) of one resolution to its sample: every frame t with hop t <= q < hop t + N
-__device__ __forceinline__ float mr_gather(const float* fr, int N, int hop, int F, long q) {
-  long t1 = q / hop;
+// contributions of padded position q (= p + N/2) of one resolution to its sample: every frame t whose window support
+// covers it, hop t + off <= q < hop t + off + win (off = (N - win) / 2), in ascending t -- a fixed order
+__device__ __forceinline__ float mr_gather(const float* fr, int N, int win, int hop, int F, long q) {
+  const long qq = q - (N - win) / 2;
+  if (qq < 0) return 0.f;
+  long t1 = qq / hop;
   if (t1 > F - 1) t1 = F - 1;
-  long t0 = q - (N - 1);
+  long t0 = qq - (win - 1);
   t0 = t0 <= 0 ? 0 : (t0 + hop - 1) / hop;
   float s = 0.f;
-  for (long t = t0; t <= t1; ++t) s += fr[t * N + (q - t * hop)];
+  for (long t = t0; t <= t1; ++t) s += fr[t * win + (qq - t * hop)];
   return s;
 }
 __global__ __launch_bounds__(256) void mr_ola_kernel(MrOlaArgs a) {
@@ -230,11 +241,11 @@ __global__ __launch_bounds__(256) void mr_ola_kernel(MrOlaArgs a) {
 #pragma unroll
     for (int r = 0; r < MR_NRES; ++r) {
       const int N = a.n[r], half = N / 2;
-      const float* fr = a.frames[r] + b * (long)a.F[r] * N;
-      s += mr_gather(fr, N, a.hop[r], a.F[r], nidx + half);                                 // the sample itself
-      if (nidx >= 1 && nidx <= half) s += mr_gather(fr, N, a.hop[r], a.F[r], half - nidx);  // left mirror: p = -n
-      const long pr = 2 * (a.L - 1) - nidx;                                                  // right mirror: p = 2(L-1) - n
-      if (nidx <= a.L - 2 && pr < a.L + half) s += mr_gather(fr, N, a.hop[r], a.F[r], pr + half);
+      const float* fr = a.frames[r] + b * (long)a.F[r] * a.win[r];
+      s += mr_gather(fr, N, a.win[r], a.hop[r], a.F[r], nidx + half);                                 // the sample itself
+      if (nidx >= 1 && nidx <= half) s += mr_gather(fr, N, a.win[r], a.hop[r], a.F[r], half - nidx);  // left mirror: p = -n
+      const long pr = 2 * (a.L - 1) - nidx;                                                            // right mirror: p = 2(L-1) - n
+      if (nidx <= a.L - 2 && pr < a.L + half) s += mr_gather(fr, N, a.win[r], a.hop[r], a.F[r], pr + half);
     }
     a.d_x[i] = s;
   }
@@ -253,7 +264,7 @@ static MrWs mr_layout(int B, long L, void* ws) {
     const int F = (int)(1 + L / MR_HOP[r]);
     w.nblk[r] = B * ((F + mr_waves(MR_NFFT[r]) - 1) / mr_waves(MR_NFFT[r]));
     w.partial[r] = take((size_t)w.nblk[r] * 3);
-    w.frames[r] = take((size_t)B * F * MR_NFFT[r]);
+    w.frames[r] = take((size_t)B * F * MR_WIN[r]);
   }
   w.total = used;
   return w;
@@ -282,6 +293,7 @@ extern "C" int svs_mrstft_loss_fwd_bwd(const float* x, const float* y, int B, in
   SVS_REQUIRE(x && y && loss && B > 0 && L > 2048, "svs_mrstft_loss_fwd_bwd: bad arguments (need L > 2048 for reflect padding)");
   const MrWs w = mr_layout(B, L, ws);
   if (!ws || ws_bytes < w.total || !svs_aligned16(ws)) { svs_set_error("svs_mrstft_loss_fwd_bwd: workspace too small (%zu < %zu)", ws_bytes, w.total); return SVS_ERR_WORKSPACE; }
+  static_assert(MrCfg<1024>::WIN == 600 && MrCfg<2048>::WIN == 1200 && MrCfg<512>::WIN == 240, "MrCfg::WIN must match MR_WIN");
   int rc;
   MrArgs a[MR_NRES];
   MrFinalArgs f{};
@@ -294,7 +306,7 @@ extern "C" int svs_mrstft_loss_fwd_bwd(const float* x, const float* y, int B, in
     f.count[r] = (double)B * a[r].F * (MR_NFFT[r] / 2 + 1);
   }
   f.grad_scale = grad_scale; f.loss = loss; f.coef = w.coef;
-  hipLaunchKernelGGL(mr_finalize_kernel, dim3(1), dim3(256), 0, stream, f);
+  hipLaunchKernelGGL(mr_finalize_kernel, dim3(1), dim3(1024), 0, stream, f);
   SVS_CHECK_LAUNCH("mr_finalize");
   if (!d_x) return SVS_OK;
   MrOlaArgs o{};
@@ -302,7 +314,7 @@ extern "C" int svs_mrstft_loss_fwd_bwd(const float* x, const float* y, int B, in
     rc = MR_NFFT[r] == 1024 ? mr_launch<1024>(true, a[r], B, stream) : MR_NFFT[r] == 2048 ? mr_launch<2048>(true, a[r], B, stream)
                                                                                              : mr_launch<512>(true, a[r], B, stream);
     if (rc) return rc;
-    o.frames[r] = w.frames[r]; o.n[r] = MR_NFFT[r]; o.hop[r] = MR_HOP[r]; o.F[r] = a[r].F;
+    o.frames[r] = w.frames[r]; o.n[r] = MR_NFFT[r]; o.hop[r] = MR_HOP[r]; o.F[r] = a[r].F; o.win[r] = MR_WIN[r];
   }
   o.B = B; o.L = L; o.d_x = d_x;
   long g = ((long)B * L + 255) / 256;
