@@ -409,46 +409,195 @@ __global__ __launch_bounds__(256) void conv1_bf16_kernel(const float* __restrict
   dst[3] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
 }
 
-// deconv6 + sigmoid (model.py:109,198-200): 32 bf16 channels -> 1 fp32 channel, gather form (each output pixel sums its
-// <= 9 in-range taps); neighbouring threads share their input lines through L1
-__global__ __launch_bounds__(256) void deconv6_bf16_kernel(const u16* __restrict__ x, long ldx, int B, int H, int W, const float* __restrict__ w /*[32][25]*/,
-                                                           const float* __restrict__ bias, float* __restrict__ y, int Ho, int Wo) {
-  __shared__ float wl[25][32];                                // [tap][c]
-  for (int i = threadIdx.x; i < 800; i += 256) wl[i % 25][i / 25] = w[i];
-  __syncthreads();
-  const long P = (long)B * Ho * Wo;
-  const long pix = (long)blockIdx.x * 256 + threadIdx.x;
-  if (pix >= P) return;
-  const int ow = (int)(pix % Wo);
-  const long tmp = pix / Wo;
-  const int oh = (int)(tmp % Ho);
-  const long b = tmp / Ho;
-  float acc = bias[0];
+// ------------------------------------------------------------------------------------------------
+// conv2 (model.py:53-57: 16 -> 32 channels, 5x5, stride 2) as an LDS-window kernel.  In the GEMM form each input element
+// travels 25/4 times through L2 and a K-tile is one tap of 32 channels, half of them the zero-weighted decoder half of the
+// interleaved level-1 buffer: 185 us at 216 tiles for 57 us of HBM traffic.  Here a block owns 8 x 16 OUTPUT pixels,
+// stages their (2*8+3) x (2*16+3) input window (the 16 skip channels only) once, split by column parity so that the 16
+// pixels of an operand fragment -- stride 2 in the image -- are consecutive 32-byte LDS slots (conflict-free ds_read_b128),
+// and walks 13 K-steps of two taps x 16 channels.  The 26 KB of weights stay in LDS while the block walks its tiles
+// (persistent blocks).  Operand roles are swapped (weights = first MFMA operand): the four accumulator registers of a
+// lane are then four consecutive CHANNELS of one pixel, which leave as one 8-byte store.
+// ------------------------------------------------------------------------------------------------
+struct Conv2WinArgs {
+  const u16* x; long ldx; int B, H, W;       // skip half of level 1 (16 channels at x, pixel pitch ldx)
+  const u16* wk;                             // [13 steps][32 n][32 k = (tap parity, channel)] bf16, scale folded
+  const float* shift; float slope;
+  u16* y; long ldy; int Ho, Wo;              // 32 channels at y
+};
+__global__ __launch_bounds__(256) void conv2_window_bf16_kernel(Conv2WinArgs p) {
+  constexpr int TH = 8, TW = 16, WR = 2 * TH + 3, WC = 2 * TW + 3, PW = TW + 2;     // window rows / columns; slots per parity plane
+  constexpr int NCH = WR * WC * 2, NST = (NCH + 255) / 256;                         // 16-byte pieces of the window
+  constexpr int NWP = 13 * 32 * 4, NWL = (NWP + 255) / 256;                         // 16-byte pieces of the weights
+  __shared__ __attribute__((aligned(16))) unsigned char win[WR * 2 * PW * 32];
+  __shared__ __attribute__((aligned(16))) unsigned char wts[13 * 32 * 64];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lrow = lane & 15, q = lane >> 4;
+  const int tiles_w = (p.Wo + TW - 1) / TW, tiles_h = (p.Ho + TH - 1) / TH;
+  const int ntiles = p.B * tiles_h * tiles_w;
 #pragma unroll
-  for (int dh = 0; dh < 3; ++dh) {
-    const int kh = (oh & 1) + 2 * dh;                         // taps with (oh + 2 - kh) even
-    const int ih = (oh + 2 - kh) >> 1;
-    if (kh > 4 || (unsigned)ih >= (unsigned)H) continue;
+  for (int k = 0; k < NWL; ++k) {                                                  // weights: row n of step s, piece swizzled by n
+    const int e = t + k * 256;
+    if (e < NWP) {
+      const int piece = e & 3, n = (e >> 2) & 31, s_ = e >> 7;
+      *(uint4*)(&wts[(s_ * 32 + n) * 64 + ((piece ^ ((n >> 1) & 3)) * 16)]) = *(const uint4*)(p.wk + (long)e * 8);
+    }
+  }
+  const int t2 = q >> 1, half = q & 1;
+  float sh[2][4];
 #pragma unroll
-    for (int dw = 0; dw < 3; ++dw) {
-      const int kw = (ow & 1) + 2 * dw;
-      const int iw = (ow + 2 - kw) >> 1;
-      if (kw > 4 || (unsigned)iw >= (unsigned)W) continue;
-      const uint4* src = (const uint4*)(x + ((b * H + ih) * W + iw) * ldx);
-      const float* wt = wl[kh * 5 + kw];
+  for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int v4 = 0; v4 < 4; ++v4) {
-        const uint4 u = src[v4];
-        const unsigned uu[4] = {u.x, u.y, u.z, u.w};
+    for (int r = 0; r < 4; ++r) sh[j][r] = p.shift[j * 16 + q * 4 + r];
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int ow0 = (tile % tiles_w) * TW, oh0 = ((tile / tiles_w) % tiles_h) * TH;
+    const long b = tile / (tiles_w * tiles_h);
+    const u16* const xb = p.x + b * p.H * p.W * p.ldx;
+    uint4 stage[NST];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          acc += __builtin_bit_cast(float, uu[e] << 16) * wt[v4 * 8 + 2 * e];
-          acc += __builtin_bit_cast(float, uu[e] & 0xFFFF0000u) * wt[v4 * 8 + 2 * e + 1];
-        }
+    for (int k = 0; k < NST; ++k) {
+      const int e = t + k * 256, hf = e & 1, px = e >> 1;
+      const int wr = px / WC, wc = px - wr * WC;
+      const int ih = 2 * oh0 - 2 + wr, iw = 2 * ow0 - 2 + wc;
+      stage[k] = make_uint4(0u, 0u, 0u, 0u);
+      if (e < NCH && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) stage[k] = *(const uint4*)(xb + ((long)ih * p.W + iw) * p.ldx + hf * 8);
+    }
+    __syncthreads();                                                               // the previous tile's readers are done
+#pragma unroll
+    for (int k = 0; k < NST; ++k) {
+      const int e = t + k * 256, hf = e & 1, px = e >> 1;
+      const int wr = px / WC, wc = px - wr * WC;
+      if (e < NCH) *(uint4*)(&win[((wr * 2 + (wc & 1)) * PW + (wc >> 1)) * 32 + hf * 16]) = stage[k];
+    }
+    __syncthreads();
+    f32x4 acc[2][2];                                                               // [pixel row i][channel tile j]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // pixel fragment of output row 2*wave + i: lane (pixel lrow, q) reads channels half*8.. of tap 2s + t2
+    const unsigned char* const pbase = &win[(((4 * wave) * 2) * PW + lrow) * 32 + half * 16];
+    const unsigned char* const wbase = &wts[lrow * 64 + ((q ^ ((lrow >> 1) & 3)) * 16)];
+    bf_static_for<13>([&](auto sc) {
+      constexpr int s_ = decltype(sc)::value;
+      constexpr int tap0 = 2 * s_, tap1 = (2 * s_ + 1 < 25) ? 2 * s_ + 1 : 24;     // (the 26th tap has zero weights: any finite data)
+      constexpr int off0 = (((tap0 / 5) * 2 + ((tap0 % 5) & 1)) * PW + ((tap0 % 5) >> 1)) * 32;
+      constexpr int off1 = (((tap1 / 5) * 2 + ((tap1 % 5) & 1)) * PW + ((tap1 % 5) >> 1)) * 32;
+      const int off = t2 ? off1 : off0;
+      bf16x8 fw[2], fp[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fw[j] = __builtin_bit_cast(bf16x8, *(const f32x4*)(wbase + (s_ * 32 + j * 16) * 64));
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fp[i] = __builtin_bit_cast(bf16x8, *(const f32x4*)(pbase + off + i * (4 * PW * 32)));
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fp[i], acc[i][j], 0, 0, 0);
+    });
+    // D map: column lrow = pixel, rows q*4 + r = channels (+16 j): 4 consecutive channels per lane -> one 8-byte store
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int oh = oh0 + 2 * wave + i, ow = ow0 + lrow;
+      if (oh >= p.Ho || ow >= p.Wo) continue;
+      u16* const dst = p.y + ((b * p.Ho + oh) * p.Wo + ow) * p.ldy + q * 4;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float u = acc[i][j][r] + sh[j][r]; v[r] = u > 0.f ? u : u * p.slope; }
+        uint2 o;
+        o.x = (unsigned)to_bf16(v[0]) | ((unsigned)to_bf16(v[1]) << 16);
+        o.y = (unsigned)to_bf16(v[2]) | ((unsigned)to_bf16(v[3]) << 16);
+        *(uint2*)(dst + j * 16) = o;
       }
     }
   }
-  y[pix] = 1.f / (1.f + __expf(-acc));
+}
+// wk[s][n][k]: k = t2*16 + c holds scale[n] * W[n][tap = 2s + t2][c] (zero for the 26th tap), from the gather-packed fp32 weights [n][25][16]
+__global__ void conv2_pack_kernel(const float* __restrict__ wp, const float* __restrict__ scale, u16* __restrict__ wk) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 13 * 32 * 32) return;
+  const int k = i & 31, n = (i >> 5) & 31, s_ = i >> 10;
+  const int tap = 2 * s_ + (k >> 4), c = k & 15;
+  wk[i] = tap < 25 ? to_bf16(wp[(n * 25 + tap) * 16 + c] * scale[n]) : (u16)0;
+}
+
+// deconv6 + sigmoid (model.py:109,198-200): 32 bf16 channels -> 1 fp32 channel, on the MFMA.  One output channel is no GEMM
+// column, but the four output parities of an anchor pixel are: out(2a + ph, 2c + pw) = sum over the 3x3 input neighbourhood of
+// (a, c) and 32 channels of x * W2[pos][ph, pw][ch], where W2 holds tap (ph + 2 - 2 dh, pw + 2 - 2 dw) or zero if that tap does
+// not exist (9 / 6 / 6 / 4 taps per parity).  So M = anchor pixels, K = 9 x 32, N = 4 (padded to the MFMA's 16 columns; the
+// padding costs nothing that matters: 72 MFMAs per 8x16-anchor block).  A block stages its (8+2) x (16+2) x 32 window once in
+// LDS (96-byte pixel pitch: the 16 pixels x 16 bytes of a ds_read_b128 group then fall on 64 distinct banks); every operand
+// fragment is one ds_read_b128.  Lanes of the columns 0..3 exchange with their pw-partner so that each writes one float4
+// of an output row.  Bound: HBM (32 ch x 2 B in, 4 x 4 B out per anchor).
+struct Deconv6Args { const u16* x; long ldx; int B, H, W; const u16* w2; const float* bias; float* y; int Ho, Wo; };
+__global__ __launch_bounds__(256) void deconv6_mfma_bf16_kernel(Deconv6Args p) {
+  constexpr int TH = 8, TW = 16, WW = TW + 2, NPX = (TH + 2) * WW, PS = 48;     // PS: u16 per staged pixel
+  __shared__ __attribute__((aligned(16))) u16 win[NPX * PS];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lrow = lane & 15, q = lane >> 4;
+  const int tiles_w = (p.W + TW - 1) / TW, tiles_h = (p.H + TH - 1) / TH;
+  const int tile = blockIdx.x;
+  const int tw0 = (tile % tiles_w) * TW, th0 = ((tile / tiles_w) % tiles_h) * TH;
+  const long b = tile / (tiles_w * tiles_h);
+  const u16* const xb = p.x + b * p.H * p.W * p.ldx;
+#pragma unroll
+  for (int k = 0; k < (NPX * 4 + 255) / 256; ++k) {
+    const int e = t + k * 256, px = e >> 2, cq = e & 3;
+    if (px >= NPX) break;
+    const int lh = px / WW, lw = px - lh * WW;
+    const int ih = th0 - 1 + lh, iw = tw0 - 1 + lw;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) v = *(const uint4*)(xb + ((long)ih * p.W + iw) * p.ldx + cq * 8);
+    *(uint4*)(&win[px * PS + cq * 8]) = v;
+  }
+  bf16x8 fb[9];
+#pragma unroll
+  for (int pos = 0; pos < 9; ++pos) fb[pos] = *(const bf16x8*)(p.w2 + (pos * 16 + lrow) * 32 + q * 8);
+  __syncthreads();
+  const float bias = p.bias[0];
+  const int ph = (lrow >> 1) & 1, pw = lrow & 1;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ah = 2 * wave + i;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int pos = 0; pos < 9; ++pos) {
+      const int dh = pos / 3, dw = pos % 3;                      // window coordinates of (anchor - 1 + d)
+      const bf16x8 fa = *(const bf16x8*)(&win[((ah + dh) * WW + lrow + dw) * PS + q * 8]);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[pos], acc, 0, 0, 0);
+    }
+    // C map: column lrow (= parity for lrow < 4), rows q*4 + r = anchors tw0 + q*4 + r
+    float own[4], oth[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      own[r] = 1.f / (1.f + __expf(-(acc[r] + bias)));
+      oth[r] = __shfl_xor(own[r], 1, 64);
+    }
+    const int oh = 2 * (th0 + ah) + ph;
+    if (lrow >= 4 || th0 + ah >= p.H || oh >= p.Ho) continue;
+    // pw = 0 writes the outputs of anchors q*4, q*4+1 (4 columns), pw = 1 those of anchors q*4+2, q*4+3
+    const int ow0 = 2 * (tw0 + q * 4) + 4 * pw;
+    const float v0 = pw ? oth[2] : own[0], v1 = pw ? own[2] : oth[0], v2 = pw ? oth[3] : own[1], v3 = pw ? own[3] : oth[1];
+    float* dst = p.y + (b * p.Ho + oh) * p.Wo + ow0;
+    if ((p.Wo & 3) == 0 && ow0 + 3 < p.Wo) *(f32x4*)dst = (f32x4){v0, v1, v2, v3};
+    else {
+      if (ow0 < p.Wo) dst[0] = v0;
+      if (ow0 + 1 < p.Wo) dst[1] = v1;
+      if (ow0 + 2 < p.Wo) dst[2] = v2;
+      if (ow0 + 3 < p.Wo) dst[3] = v3;
+    }
+  }
+}
+// W2[pos = (dh+1)*3 + (dw+1)][n = ph*2 + pw (rows 4..15 zero)][ch] from the torch-layout fp32 weights [ch][kh*5 + kw]
+__global__ void deconv6_pack_kernel(const float* __restrict__ w, u16* __restrict__ w2) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 9 * 16 * 32) return;
+  const int c = i & 31, n = (i >> 5) & 15, pos = i >> 9;
+  float v = 0.f;
+  if (n < 4) {
+    const int kh = (n >> 1) + 2 - 2 * (pos / 3 - 1), kw = (n & 1) + 2 - 2 * (pos % 3 - 1);
+    if (kh >= 0 && kh <= 4 && kw >= 0 && kw <= 4) v = w[c * 25 + kh * 5 + kw];
+  }
+  w2[i] = to_bf16(v);
 }
 
 // packed fp32 weights (gather [n][25][c] or parity [class][n][taps][c]) times the folded BatchNorm scale of output channel n
@@ -550,7 +699,7 @@ static int conv_bf16_run(int mode, const u16* x, long ldx, int B, int H, int W, 
 static const int BCH[7] = {1, 16, 32, 64, 128, 256, 512};
 static const int BDEC_C[6] = {512, 512, 256, 128, 64, 32};
 static const int BDEC_N[6] = {256, 128, 64, 32, 16, 1};
-struct Bf16Prepared { long w[12], shift[11], w1, w6, bias6, total; };          // byte offsets into the prepared blob
+struct Bf16Prepared { long w[12], shift[11], w1, w2k, w6, bias6, total; };          // byte offsets into the prepared blob
 static Bf16Prepared bf16_prepared_layout() {
   Bf16Prepared L{};
   long off = 0;
@@ -558,7 +707,8 @@ static Bf16Prepared bf16_prepared_layout() {
   L.w1 = take(16 * 25 * 4);                                    // conv1: fp32 [16][25], scale folded
   for (int k = 2; k <= 6; ++k) L.w[k - 1] = take((long)BCH[k] * (k == 2 ? 32 : BCH[k - 1]) * 25 * 2);
   for (int j = 0; j < 5; ++j) L.w[6 + j] = take((long)BDEC_C[j] * BDEC_N[j] * 25 * 2);
-  L.w6 = take(32 * 25 * 4);                                    // deconv6: fp32 [32][25] (torch layout)
+  L.w2k = take(13 * 32 * 32 * 2);                              // conv2, window kernel: bf16 [13 steps][32 n][2 taps x 16 channels]
+  L.w6 = take(9 * 16 * 32 * 2);                                // deconv6: bf16 [9 positions][16 columns (4 parities used)][32 channels]
   for (int l = 0; l < 11; ++l) L.shift[l] = take((l < 6 ? BCH[l + 1] : BDEC_N[l - 6]) * 4);
   L.bias6 = take(4);
   L.total = off;
@@ -591,7 +741,10 @@ extern "C" int svs_unet_prepare_eval_bf16(const void* prepared_f32, void* prepar
                        BDEC_C[j], BDEC_C[j], 1);
     SVS_CHECK_LAUNCH("pack_bf16");
   }
-  SVS_HIP(hipMemcpyAsync(out + L.w6, blob + wp[11], 32 * 25 * 4, hipMemcpyDeviceToDevice, stream));
+  hipLaunchKernelGGL(conv2_pack_kernel, dim3(52), dim3(256), 0, stream, blob + wp[1], blob + scale[1], (u16*)(out + L.w2k));
+  SVS_CHECK_LAUNCH("conv2_pack");
+  hipLaunchKernelGGL(deconv6_pack_kernel, dim3(18), dim3(256), 0, stream, blob + wp[11], (u16*)(out + L.w6));
+  SVS_CHECK_LAUNCH("deconv6_pack");
   SVS_HIP(hipMemcpyAsync(out + L.bias6, blob + bias6, 4, hipMemcpyDeviceToDevice, stream));
   for (int l = 0; l < 11; ++l)
     SVS_HIP(hipMemcpyAsync(out + L.shift[l], blob + shift[l], (l < 6 ? BCH[l + 1] : BDEC_N[l - 6]) * 4, hipMemcpyDeviceToDevice, stream));
@@ -638,6 +791,13 @@ extern "C" int svs_unet_forward_eval_bf16(const void* prepared_bf16, const float
                      e.cat[1], 32L, e.h[1], e.w[1]);
   SVS_CHECK_LAUNCH("conv1_bf16");
   for (int k = 2; k <= 6; ++k) {
+    if (k == 2 && svs_tune(SVS_TUNE_CONV_WINDOW) != 0 && (long)e.h[1] * e.w[1] * 32 * 2 < (1L << 31)) {      // LDS-window kernel on the skip half alone
+      Conv2WinArgs c{e.cat[1] + 16, 32L, B, e.h[1], e.w[1], (const u16*)(blob + L.w2k), SH(1), 0.2f, e.cat[2] + 32, 64L, e.h[2], e.w[2]};
+      const long tiles = (long)B * ((e.h[2] + 7) / 8) * ((e.w[2] + 15) / 16);
+      hipLaunchKernelGGL(conv2_window_bf16_kernel, dim3((unsigned)(tiles < 768 ? tiles : 768)), dim3(256), 0, stream, c);
+      SVS_CHECK_LAUNCH("conv2_window_bf16");
+      continue;
+    }
     const int C = k == 2 ? 32 : BCH[k - 1];
     const u16* x = k == 2 ? e.cat[1] : e.cat[k - 1] + BCH[k - 1];        // skip half (second) of the level below; level 1: all 32 (see above)
     const long ldx = 2L * BCH[k - 1];
@@ -654,8 +814,11 @@ extern "C" int svs_unet_forward_eval_bf16(const void* prepared_bf16, const float
                             2L * BCH[lout], e.h[lout], e.w[lout], BDEC_N[j], e.scratch, e.scratch_bytes, stream))) return rc;
   }
   // deconv6 + sigmoid (model.py:198-200)
-  hipLaunchKernelGGL(deconv6_bf16_kernel, dim3((unsigned)((e.P[0] + 255) / 256)), dim3(256), 0, stream, e.cat[1], 32L, B, e.h[1], e.w[1],
-                     (const float*)(blob + L.w6), (const float*)(blob + L.bias6), mask, H, W);
-  SVS_CHECK_LAUNCH("deconv6_bf16");
+  {
+    Deconv6Args d{e.cat[1], 32L, B, e.h[1], e.w[1], (const u16*)(blob + L.w6), (const float*)(blob + L.bias6), mask, H, W};
+    const long tiles = (long)B * ((e.h[1] + 7) / 8) * ((e.w[1] + 15) / 16);
+    hipLaunchKernelGGL(deconv6_mfma_bf16_kernel, dim3((unsigned)tiles), dim3(256), 0, stream, d);
+    SVS_CHECK_LAUNCH("deconv6_mfma_bf16");
+  }
   return SVS_OK;
 }
