@@ -152,38 +152,42 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_kernel(ConvBf16Args p) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);   // weights first: see the epilogue
     if (more) store_tile(buf ^ 1);
     __syncthreads();
   }
-  // epilogue: C/D map col = lane & 15, row = 4 (lane >> 4) + reg
+  // epilogue.  The weights are the FIRST MFMA operand, so the D tile is [channel][pixel]: column lane & 15 = GEMM row (pixel),
+  // rows 4 (lane >> 4) + reg = four CONSECUTIVE output channels -- one 8-byte bf16 store (or one 16-byte slab store) per lane
+  // and tile instead of four 2-byte ones, and one pixel decode per lane and row tile
   const bool split = p.ksplit > 1;
   float* const slab = split ? p.slab + (long)blockIdx.y * ((long)p.B * p.Ho * p.Wo) * p.N : nullptr;
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const long m = m0 + wm * (TM * 16) + i * 16 + q * 4 + r;
-      if (m >= M) continue;
-      long opix;
-      if (MODE == BF_GATHER) opix = m;
-      else {
-        const int wq = (int)(m % Wa);
-        const long tmp = m / Wa;
-        const int hq = (int)(tmp % Ha);
-        const long b = tmp / Ha;
-        opix = (b * p.Ho + 2 * hq + ph) * p.Wo + 2 * wq + pw;
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * (TN * 16) + j * 16 + lrow;
-        float v = acc[i][j][r];
-        if (split) { slab[opix * p.N + n] = v; continue; }
-        v += p.shift[n];
-        v = v > 0.f ? v : v * p.slope;
-        p.y[opix * p.ldy + n] = to_bf16(v);
-      }
+  for (int i = 0; i < TM; ++i) {
+    const long m = m0 + wm * (TM * 16) + i * 16 + lrow;
+    if (m >= M) continue;
+    long opix;
+    if (MODE == BF_GATHER) opix = m;
+    else {
+      const int wq = (int)(m % Wa);
+      const long tmp = m / Wa;
+      const int hq = (int)(tmp % Ha);
+      const long b = tmp / Ha;
+      opix = (b * p.Ho + 2 * hq + ph) * p.Wo + 2 * wq + pw;
     }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * (TN * 16) + j * 16 + q * 4;
+      if (split) { *(f32x4*)(slab + opix * p.N + n) = acc[i][j]; continue; }
+      const f32x4 sh = *(const f32x4*)(p.shift + n);
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const float u = acc[i][j][r] + sh[r]; v[r] = u > 0.f ? u : u * p.slope; }
+      uint2 o;
+      o.x = (unsigned)to_bf16(v[0]) | ((unsigned)to_bf16(v[1]) << 16);
+      o.y = (unsigned)to_bf16(v[2]) | ((unsigned)to_bf16(v[3]) << 16);
+      *(uint2*)(p.y + opix * p.ldy + n) = o;
+    }
+  }
 }
 
 
@@ -301,28 +305,34 @@ __global__ __launch_bounds__(256) void parity_window_bf16_kernel(ConvBf16Args p)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);   // weights first: see store_class
     }
   };
-  // rows q*4 + r of row tile i = anchor (th0 + 2 wave + i, tw0 + q*4 + r); column lrow (+16 j) = output channel
-  auto store_class = [&](int par, const f32x4 (&acc)[TM][TN]) {
+  // The weights are the FIRST MFMA operand, so the D tile is [channel][pixel]: column lrow = anchor (th0 + 2 wave + i, tw0 + lrow),
+  // rows q*4 + r = output channels (+16 j) -- four consecutive channels per lane, one 8-byte store (2-byte stores of one
+  // channel per lane were most of the kernel's time: deconv5 134 -> us at 216 tiles)
+  float shv[TN][4];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) shv[j][r] = p.shift[j * 16 + q * 4 + r];
+  auto store_class = [&](int par, const f32x4 (&acc)[TM][TN]) __attribute__((always_inline)) {
     const int ph = par >> 1, pw = par & 1;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int a = th0 + 2 * wave + i, oh = 2 * a + ph;
-      if (a >= p.H || oh >= p.Ho) continue;
+      const int c = tw0 + lrow, ow = 2 * c + pw;
+      if (a >= p.H || oh >= p.Ho || c >= p.W || ow >= p.Wo) continue;
+      u16* const dst = p.y + ((b * p.Ho + oh) * p.Wo + ow) * p.ldy + q * 4;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int c = tw0 + q * 4 + r, ow = 2 * c + pw;
-        if (c >= p.W || ow >= p.Wo) continue;
-        const long opix = (b * p.Ho + oh) * p.Wo + ow;
+      for (int j = 0; j < TN; ++j) {
+        float v[4];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int n = j * 16 + lrow;
-          float v = acc[i][j][r] + p.shift[n];
-          v = v > 0.f ? v : v * p.slope;
-          p.y[opix * p.ldy + n] = to_bf16(v);
-        }
+        for (int r = 0; r < 4; ++r) { const float u = acc[i][j][r] + shv[j][r]; v[r] = u > 0.f ? u : u * p.slope; }
+        uint2 o;
+        o.x = (unsigned)to_bf16(v[0]) | ((unsigned)to_bf16(v[1]) << 16);
+        o.y = (unsigned)to_bf16(v[2]) | ((unsigned)to_bf16(v[3]) << 16);
+        *(uint2*)(dst + j * 16) = o;
       }
     }
   };
