@@ -382,41 +382,67 @@ __global__ __launch_bounds__(256) void splitk_epilogue_bf16_kernel(const float* 
   }
 }
 
-// conv1 (model.py:47-51): 1 -> 16 channels, fp32 input tile; writes the whole 32-channel level-1 pixel: zeros in the
-// decoder half [0, 16) (conv2 reads it against zero weights before deconv5 fills it), the activations in [16, 32)
-__global__ __launch_bounds__(256) void conv1_bf16_kernel(const float* __restrict__ x, int B, int H, int W, const float* __restrict__ w /*[16][25] scale folded*/,
-                                                         const float* __restrict__ shift, float slope, u16* __restrict__ y, long ldy, int Ho, int Wo) {
-  const long P = (long)B * Ho * Wo;
-  const long pix = (long)blockIdx.x * 256 + threadIdx.x;
-  if (pix >= P) return;
-  const int ow = (int)(pix % Wo);
-  const long tmp = pix / Wo;
-  const int oh = (int)(tmp % Ho);
-  const long b = tmp / Ho;
-  const float* img = x + b * H * W;
-  float xin[25];
-#pragma unroll
-  for (int kh = 0; kh < 5; ++kh)
-#pragma unroll
-    for (int kw = 0; kw < 5; ++kw) {
-      const int ih = 2 * oh - 2 + kh, iw = 2 * ow - 2 + kw;
-      xin[kh * 5 + kw] = ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) ? img[(long)ih * W + iw] : 0.f;
-    }
-  unsigned pk[8];
-#pragma unroll
-  for (int n = 0; n < 16; n += 2) {
-    float a0 = shift[n], a1 = shift[n + 1];
-#pragma unroll
-    for (int tap = 0; tap < 25; ++tap) { a0 += xin[tap] * w[n * 25 + tap]; a1 += xin[tap] * w[(n + 1) * 25 + tap]; }
-    a0 = a0 > 0.f ? a0 : a0 * slope;
-    a1 = a1 > 0.f ? a1 : a1 * slope;
-    pk[n >> 1] = (unsigned)to_bf16(a0) | ((unsigned)to_bf16(a1) << 16);
+// conv1 (model.py:47-51): 1 -> 16 channels, 5x5, stride 2, fp32 input tile -> the skip half [16, 32) of the interleaved level-1
+// pixel.  One input channel gives no channel reduction, so the K of the MFMA is the 25 taps (padded to 32): first operand =
+// weights [16 n][32 k], second = the im2col patch of 16 output pixels, gathered from an fp32 LDS window (lane (pixel, q) reads
+// the taps 8q .. 8q+7 of its patch).  The input keeps its fp32 information: x = hi + lo in two bf16 limbs, two MFMAs per 16
+// pixels against the same weights.  400 FMAs per pixel on the VALU (118 us at 216 tiles) become two MFMAs per 16 pixels; what
+// is left is the gather (8 ds_read_b32 + ~24 VALU per lane) and HBM: 57 MB in, 113 MB out.
+struct Conv1Args { const float* x; int B, H, W; const u16* w1b; const float* shift; float slope; u16* y; long ldy; int Ho, Wo; };
+__global__ __launch_bounds__(256) void conv1_mfma_bf16_kernel(Conv1Args p) {
+  constexpr int TH = 16, TW = 32, WR = 2 * TH + 3, WC = 2 * TW + 4;              // window rows; columns (67 used)
+  __shared__ float win[WR * WC];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lrow = lane & 15, q = lane >> 4;
+  const int tiles_w = (p.Wo + TW - 1) / TW, tiles_h = (p.Ho + TH - 1) / TH;
+  const int tile = blockIdx.x;
+  const int ow0 = (tile % tiles_w) * TW, oh0 = ((tile / tiles_w) % tiles_h) * TH;
+  const long b = tile / (tiles_w * tiles_h);
+  const float* const img = p.x + b * p.H * p.W;
+  for (int e = t; e < WR * WC; e += 256) {
+    const int wr = e / WC, wc = e - wr * WC;
+    const int ih = 2 * oh0 - 2 + wr, iw = 2 * ow0 - 2 + wc;
+    win[e] = ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) ? img[(long)ih * p.W + iw] : 0.f;
   }
-  uint4* dst = (uint4*)(y + pix * ldy);
-  dst[0] = make_uint4(0u, 0u, 0u, 0u);
-  dst[1] = make_uint4(0u, 0u, 0u, 0u);
-  dst[2] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-  dst[3] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+  const bf16x8 fw = *(const bf16x8*)(p.w1b + lrow * 32 + q * 8);
+  int off[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { const int k = q * 8 + e < 25 ? q * 8 + e : 24; off[e] = (k / 5) * WC + (k % 5); }   // (taps 25..31: zero weights)
+  const f32x4 sh = *(const f32x4*)(p.shift + q * 4);
+  __syncthreads();
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {                                                  // wave: output rows 4 wave .. 4 wave + 3, two 16-pixel groups each
+    const int ohl = 4 * wave + (g >> 1), owl = (g & 1) * 16 + lrow;
+    const float* const base = &win[(2 * ohl) * WC + 2 * owl];
+    float xv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) xv[e] = base[off[e]];
+    unsigned hi[4], lo[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      hi[h] = (unsigned)to_bf16(xv[2 * h]) | ((unsigned)to_bf16(xv[2 * h + 1]) << 16);
+      const float r0 = xv[2 * h] - __builtin_bit_cast(float, hi[h] << 16), r1 = xv[2 * h + 1] - __builtin_bit_cast(float, hi[h] & 0xffff0000u);
+      lo[h] = (unsigned)to_bf16(r0) | ((unsigned)to_bf16(r1) << 16);
+    }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw, __builtin_bit_cast(bf16x8, (uint4){lo[0], lo[1], lo[2], lo[3]}), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw, __builtin_bit_cast(bf16x8, (uint4){hi[0], hi[1], hi[2], hi[3]}), acc, 0, 0, 0);
+    const int oh = oh0 + ohl, ow = ow0 + owl;
+    if (oh >= p.Ho || ow >= p.Wo) continue;
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const float u = acc[r] + sh[r]; v[r] = u > 0.f ? u : u * p.slope; }
+    uint2 o;
+    o.x = (unsigned)to_bf16(v[0]) | ((unsigned)to_bf16(v[1]) << 16);
+    o.y = (unsigned)to_bf16(v[2]) | ((unsigned)to_bf16(v[3]) << 16);
+    *(uint2*)(p.y + ((b * p.Ho + oh) * p.Wo + ow) * p.ldy + q * 4) = o;
+  }
+}
+// w1b[n][k]: scale[n] * W[n][tap k] for k < 25, zero for the padding taps
+__global__ void conv1_pack_kernel(const float* __restrict__ w, const float* __restrict__ scale, u16* __restrict__ w1b) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 16 * 32) return;
+  const int k = i & 31, n = i >> 5;
+  w1b[i] = k < 25 ? to_bf16(w[n * 25 + k] * scale[n]) : (u16)0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -714,8 +740,8 @@ static Bf16Prepared bf16_prepared_layout() {
   Bf16Prepared L{};
   long off = 0;
   auto take = [&](long bytes) { long o = off; off += (bytes + 255) / 256 * 256; return o; };
-  L.w1 = take(16 * 25 * 4);                                    // conv1: fp32 [16][25], scale folded
-  for (int k = 2; k <= 6; ++k) L.w[k - 1] = take((long)BCH[k] * (k == 2 ? 32 : BCH[k - 1]) * 25 * 2);
+  L.w1 = take(16 * 32 * 2);                                    // conv1: bf16 [16 n][32 taps (25 used)], scale folded
+  for (int k = 3; k <= 6; ++k) L.w[k - 1] = take((long)BCH[k] * BCH[k - 1] * 25 * 2);      // (conv2 has its own form: w2k)
   for (int j = 0; j < 5; ++j) L.w[6 + j] = take((long)BDEC_C[j] * BDEC_N[j] * 25 * 2);
   L.w2k = take(13 * 32 * 32 * 2);                              // conv2, window kernel: bf16 [13 steps][32 n][2 taps x 16 channels]
   L.w6 = take(9 * 16 * 32 * 2);                                // deconv6: bf16 [9 positions][16 columns (4 parities used)][32 channels]
@@ -726,11 +752,6 @@ static Bf16Prepared bf16_prepared_layout() {
 }
 extern "C" size_t svs_unet_prepared_bf16_bytes(void) { return (size_t)bf16_prepared_layout().total; }
 
-__global__ void fold_conv1_kernel(const float* __restrict__ w, const float* __restrict__ scale, float* __restrict__ out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < 400) out[i] = w[i] * scale[i / 25];
-}
-
 // prepared_f32: the blob of svs_unet_prepare_eval (packed fp32 weights + folded scale / shift); this adds the bf16 forms
 extern "C" int svs_unet_prepare_eval_bf16(const void* prepared_f32, void* prepared_bf16, hipStream_t stream) {
   SVS_REQUIRE(prepared_f32 && prepared_bf16 && svs_aligned16(prepared_bf16), "svs_unet_prepare_eval_bf16: bad pointers");
@@ -739,11 +760,11 @@ extern "C" int svs_unet_prepare_eval_bf16(const void* prepared_f32, void* prepar
   const float* blob = (const float*)prepared_f32;
   long wp[12], scale[11], shift[11], bias6;
   svs_unet_prepared_offsets(wp, scale, shift, &bias6);
-  hipLaunchKernelGGL(fold_conv1_kernel, dim3(2), dim3(256), 0, stream, blob + wp[0], blob + scale[0], (float*)(out + L.w1));
-  SVS_CHECK_LAUNCH("fold_conv1");
-  for (int k = 2; k <= 6; ++k) {
-    const int N = BCH[k], C = BCH[k - 1], cpad = k == 2 ? 32 : C;
-    hipLaunchKernelGGL(pack_bf16_kernel, dim3(512), dim3(256), 0, stream, blob + wp[k - 1], blob + scale[k - 1], (u16*)(out + L.w[k - 1]), N, C, cpad, 0);
+  hipLaunchKernelGGL(conv1_pack_kernel, dim3(2), dim3(256), 0, stream, blob + wp[0], blob + scale[0], (u16*)(out + L.w1));
+  SVS_CHECK_LAUNCH("conv1_pack");
+  for (int k = 3; k <= 6; ++k) {
+    const int N = BCH[k], C = BCH[k - 1];
+    hipLaunchKernelGGL(pack_bf16_kernel, dim3(512), dim3(256), 0, stream, blob + wp[k - 1], blob + scale[k - 1], (u16*)(out + L.w[k - 1]), N, C, C, 0);
     SVS_CHECK_LAUNCH("pack_bf16");
   }
   for (int j = 0; j < 5; ++j) {
@@ -772,7 +793,7 @@ static int bf16_ws_layout(int B, int H, int W, void* ws, Bf16Ws& e) {
   for (int k = 1; k <= 5; ++k) e.cat[k] = (u16*)take((size_t)e.P[k] * 2 * BCH[k] * 2);
   e.c6 = (u16*)take((size_t)e.P[6] * 512 * 2);
   size_t sb = 0;
-  for (int k = 2; k <= 6; ++k) { const size_t s = bf16_layer_ws(BF_GATHER, B, e.h[k - 1], e.w[k - 1], k == 2 ? 32 : BCH[k - 1], e.h[k], e.w[k], BCH[k]); if (s > sb) sb = s; }
+  for (int k = 3; k <= 6; ++k) { const size_t s = bf16_layer_ws(BF_GATHER, B, e.h[k - 1], e.w[k - 1], BCH[k - 1], e.h[k], e.w[k], BCH[k]); if (s > sb) sb = s; }
   for (int j = 0; j < 5; ++j) { const size_t s = bf16_layer_ws(BF_PARITY, B, e.h[6 - j], e.w[6 - j], BDEC_C[j], e.h[5 - j], e.w[5 - j], BDEC_N[j]); if (s > sb) sb = s; }
   e.scratch_bytes = sb;
   e.scratch = take(sb + 256);
@@ -795,25 +816,26 @@ extern "C" int svs_unet_forward_eval_bf16(const void* prepared_bf16, const float
   const Bf16Prepared L = bf16_prepared_layout();
   const char* blob = (const char*)prepared_bf16;
   auto SH = [&](int l) { return (const float*)(blob + L.shift[l]); };
-  // encoder (model.py:176-181).  Level 1 is [decoder 16 | skip 16]: conv2 multiplies the decoder half by zero weights, so it
-  // must hold finite numbers -- conv1 writes zeros there
-  hipLaunchKernelGGL(conv1_bf16_kernel, dim3((unsigned)((e.P[1] + 255) / 256)), dim3(256), 0, stream, mix, B, H, W, (const float*)(blob + L.w1), SH(0), 0.2f,
-                     e.cat[1], 32L, e.h[1], e.w[1]);
-  SVS_CHECK_LAUNCH("conv1_bf16");
-  for (int k = 2; k <= 6; ++k) {
-    if (k == 2 && svs_tune(SVS_TUNE_CONV_WINDOW) != 0 && (long)e.h[1] * e.w[1] * 32 * 2 < (1L << 31)) {      // LDS-window kernel on the skip half alone
-      Conv2WinArgs c{e.cat[1] + 16, 32L, B, e.h[1], e.w[1], (const u16*)(blob + L.w2k), SH(1), 0.2f, e.cat[2] + 32, 64L, e.h[2], e.w[2]};
-      const long tiles = (long)B * ((e.h[2] + 7) / 8) * ((e.w[2] + 15) / 16);
-      hipLaunchKernelGGL(conv2_window_bf16_kernel, dim3((unsigned)(tiles < 768 ? tiles : 768)), dim3(256), 0, stream, c);
-      SVS_CHECK_LAUNCH("conv2_window_bf16");
-      continue;
-    }
-    const int C = k == 2 ? 32 : BCH[k - 1];
-    const u16* x = k == 2 ? e.cat[1] : e.cat[k - 1] + BCH[k - 1];        // skip half (second) of the level below; level 1: all 32 (see above)
+  // encoder (model.py:176-181).  Every level is one interleaved buffer [decoder half | skip half]; conv_k writes the skip half of
+  // level k and reads the skip half of level k - 1.  conv1 and conv2 have kernels of their own (1 and 16 input channels)
+  {
+    Conv1Args c{mix, B, H, W, (const u16*)(blob + L.w1), SH(0), 0.2f, e.cat[1] + 16, 32L, e.h[1], e.w[1]};
+    const long tiles = (long)B * ((e.h[1] + 15) / 16) * ((e.w[1] + 31) / 32);
+    hipLaunchKernelGGL(conv1_mfma_bf16_kernel, dim3((unsigned)tiles), dim3(256), 0, stream, c);
+    SVS_CHECK_LAUNCH("conv1_mfma_bf16");
+  }
+  {
+    Conv2WinArgs c{e.cat[1] + 16, 32L, B, e.h[1], e.w[1], (const u16*)(blob + L.w2k), SH(1), 0.2f, e.cat[2] + 32, 64L, e.h[2], e.w[2]};
+    const long tiles = (long)B * ((e.h[2] + 7) / 8) * ((e.w[2] + 15) / 16);
+    hipLaunchKernelGGL(conv2_window_bf16_kernel, dim3((unsigned)(tiles < 768 ? tiles : 768)), dim3(256), 0, stream, c);
+    SVS_CHECK_LAUNCH("conv2_window_bf16");
+  }
+  for (int k = 3; k <= 6; ++k) {
+    const u16* x = e.cat[k - 1] + BCH[k - 1];
     const long ldx = 2L * BCH[k - 1];
     u16* y = k == 6 ? e.c6 : e.cat[k] + BCH[k];
     const long ldy = k == 6 ? 512 : 2L * BCH[k];
-    if ((rc = conv_bf16_run(BF_GATHER, x, ldx, B, e.h[k - 1], e.w[k - 1], C, (const u16*)(blob + L.w[k - 1]), SH(k - 1), 0.2f, y, ldy, e.h[k], e.w[k],
+    if ((rc = conv_bf16_run(BF_GATHER, x, ldx, B, e.h[k - 1], e.w[k - 1], BCH[k - 1], (const u16*)(blob + L.w[k - 1]), SH(k - 1), 0.2f, y, ldy, e.h[k], e.w[k],
                             BCH[k], e.scratch, e.scratch_bytes, stream))) return rc;
   }
   // decoder (model.py:183-196); Dropout2d is the identity in eval
