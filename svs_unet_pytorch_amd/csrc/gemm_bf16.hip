@@ -227,22 +227,28 @@ __global__ __launch_bounds__(256) void parity_window_bf16_kernel(ConvBf16Args p)
   // block instead of once per tile (51 KB per 128 anchors was most of the L2 traffic)
   int th0 = 0, tw0 = 0;
   long b = 0;
-  auto stage_window = [&](int tile) {
-    tw0 = (tile % tiles_w) * TW;
-    th0 = ((tile / tiles_w) % tiles_h) * TH;
-    b = tile / (tiles_w * tiles_h);
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + b * p.H * p.W * p.ldx), 0, OOB, 0x00020000);
-    f32x4 stage[NST];
+  // The window of the NEXT tile is requested (global -> registers) before the current tile's taps run and written to LDS
+  // after them: with one tile in flight per block the ~2 us of load latency were as long as the tile's MFMAs.
+  f32x4 stage[NST];
+  auto fetch_window = [&](int tile) __attribute__((always_inline)) {
+    const int ftw0 = (tile % tiles_w) * TW, fth0 = ((tile / tiles_w) % tiles_h) * TH;
+    const long fb_ = tile / (tiles_w * tiles_h);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + fb_ * p.H * p.W * p.ldx), 0, OOB, 0x00020000);
 #pragma unroll
     for (int k = 0; k < NST; ++k) {
       const int e = t + k * 256;
       const int cq = e % CQ, px = e / CQ;
       const int lw = px % WW, lh = px / WW;
-      const int ih = th0 - 1 + lh, iw = tw0 - 1 + lw;
+      const int ih = fth0 - 1 + lh, iw = ftw0 - 1 + lw;
       const bool ok = px < NPX && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
       const unsigned vo = ok ? (unsigned)(((ih * p.W + iw) * (int)p.ldx + cq * 8) * 2) : OOB;
       stage[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)vo, 0, 0));
     }
+  };
+  auto commit_window = [&](int tile) __attribute__((always_inline)) {           // registers -> LDS; this tile becomes the current one
+    tw0 = (tile % tiles_w) * TW;
+    th0 = ((tile / tiles_w) % tiles_h) * TH;
+    b = tile / (tiles_w * tiles_h);
 #pragma unroll
     for (int k = 0; k < NST; ++k) {
       const int e = t + k * 256;
@@ -267,9 +273,13 @@ __global__ __launch_bounds__(256) void parity_window_bf16_kernel(ConvBf16Args p)
   constexpr bool WALL = WSWZ;
   constexpr int NBUF = WALL ? 25 : 2;
   __shared__ __attribute__((aligned(16))) unsigned char wts[NBUF][N * WPB];
-  f32x4 wreg[NWL];
-  auto fetch_w = [&](auto sc) {                                     // global -> registers: weights of step sc
+  // per-tap weights (deconv4): DEPTH register sets, so that the request for tap s + DEPTH (wrapping into the next tile: the
+  // weights do not depend on the tile) is in flight during DEPTH taps -- with one tap ahead every tap waited an L2 round trip
+  constexpr int DEPTH = WALL ? 1 : 5;
+  f32x4 wreg[DEPTH][NWL];
+  auto fetch_w = [&](auto sc, auto setc) __attribute__((always_inline)) {         // global -> register set: weights of step sc
     constexpr int s_ = decltype(sc)::value;
+    constexpr int set_ = decltype(setc)::value;
     constexpr int par = s_ < 9 ? 0 : s_ < 15 ? 1 : s_ < 21 ? 2 : 3;
     constexpr int tap = s_ - POFF[par];
     constexpr int ntaps = (3 - (par >> 1)) * (3 - (par & 1));
@@ -277,24 +287,25 @@ __global__ __launch_bounds__(256) void parity_window_bf16_kernel(ConvBf16Args p)
     for (int k = 0; k < NWL; ++k) {
       const int e = t + k * 256, n = e / CQ, cq = e - n * CQ;
       const unsigned vo = e < WCH ? (unsigned)((n * ntaps * C + cq * 8) * 2) : OOB;
-      wreg[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (int)vo, (POFF[par] * N * C + tap * C) * 2, 0));
+      wreg[set_][k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (int)vo, (POFF[par] * N * C + tap * C) * 2, 0));
     }
   };
-  auto stash_w = [&](int buf) {
+  auto stash_w = [&](int buf, auto setc) __attribute__((always_inline)) {
+    constexpr int set_ = decltype(setc)::value;
 #pragma unroll
     for (int k = 0; k < NWL; ++k) {
       const int e = t + k * 256, n = e / CQ, cq = e - n * CQ;
-      if (e < WCH) *(f32x4*)(&wts[buf][n * WPB + wpos(n, cq) * 16]) = wreg[k];
+      if (e < WCH) *(f32x4*)(&wts[buf][n * WPB + wpos(n, cq) * 16]) = wreg[set_][k];
     }
   };
-  auto step = [&](auto sc, f32x4 (&acc)[TM][TN]) {
+  auto step = [&](auto sc, f32x4 (&acc)[TM][TN], int wbuf) {
     constexpr int s_ = decltype(sc)::value;
     constexpr int par = s_ < 9 ? 0 : s_ < 15 ? 1 : s_ < 21 ? 2 : 3;
     constexpr int tap = s_ - POFF[par];
     constexpr int ntw = 3 - (par & 1);
     constexpr int th = tap / ntw, tw = tap % ntw;
     constexpr int aoff = ((1 - th) * WW + (1 - tw)) * LPB;
-    const unsigned char* wb = &wts[WALL ? s_ : (s_ & 1)][lrow * WPB];
+    const unsigned char* wb = &wts[WALL ? s_ : wbuf][lrow * WPB];
 #pragma unroll
     for (int cc = 0; cc < CC; ++cc) {
       bf16x8 fa[TM], fb[TN];
@@ -337,32 +348,37 @@ __global__ __launch_bounds__(256) void parity_window_bf16_kernel(ConvBf16Args p)
     }
   };
   f32x4 acc[TM][TN];
-  if constexpr (WALL) bf_static_for<25>([&](auto sc) { fetch_w(sc); stash_w(decltype(sc)::value); });
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-  __syncthreads();                             // the previous tile's readers are done with the window (and weight buffers)
-  stage_window(tile);
-  if constexpr (!WALL) {
-    fetch_w(std::integral_constant<int, 0>{});
-    stash_w(0);
+  using I0 = std::integral_constant<int, 0>;
+  if constexpr (WALL) bf_static_for<25>([&](auto sc) { fetch_w(sc, I0{}); stash_w(decltype(sc)::value, I0{}); });
+  else {
+    bf_static_for<DEPTH>([&](auto sc) { fetch_w(sc, sc); });
+    stash_w(0, I0{});
   }
-  __syncthreads();
-  bf_static_for<25>([&](auto sc) {
-    constexpr int s_ = decltype(sc)::value;
-    constexpr int par = s_ < 9 ? 0 : s_ < 15 ? 1 : s_ < 21 ? 2 : 3;
-    if constexpr (s_ == POFF[par]) {
+  int gstep = 0;                               // taps done so far (all tiles): its parity is the weight buffer of the current tap
+  if ((int)blockIdx.x < ntiles) fetch_window(blockIdx.x);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    if constexpr (WALL) __syncthreads();       // the previous tile's readers are done with the window (per-tap kernels: the tap barrier)
+    commit_window(tile);
+    if (tile + (int)gridDim.x < ntiles) fetch_window(tile + gridDim.x);
+    __syncthreads();
+    bf_static_for<25>([&](auto sc) {
+      constexpr int s_ = decltype(sc)::value;
+      constexpr int par = s_ < 9 ? 0 : s_ < 15 ? 1 : s_ < 21 ? 2 : 3;
+      if constexpr (s_ == POFF[par]) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-    if constexpr (!WALL && s_ + 1 < 25) fetch_w(std::integral_constant<int, (s_ + 1 < 25 ? s_ + 1 : 0)>{});   // in flight during this tap's MFMAs
-    step(sc, acc);
-    if constexpr (s_ == 24 || s_ + 1 == POFF[par < 3 ? par + 1 : 3]) store_class(par, acc);
-    if constexpr (!WALL && s_ + 1 < 25) {
-      stash_w((s_ + 1) & 1);                   // the other buffer: its last readers passed the barrier that ended tap s - 1
-      __syncthreads();
-    }
-  });
+          for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+      if constexpr (!WALL) fetch_w(std::integral_constant<int, (s_ + DEPTH) % 25>{}, std::integral_constant<int, s_ % DEPTH>{});
+      step(sc, acc, gstep & 1);
+      if constexpr (s_ == 24 || s_ + 1 == POFF[par < 3 ? par + 1 : 3]) store_class(par, acc);
+      if constexpr (!WALL) {
+        stash_w((gstep + 1) & 1, std::integral_constant<int, (s_ + 1) % DEPTH>{});   // the other buffer: its last readers passed the barrier that ended the previous tap
+        __syncthreads();
+        ++gstep;
+      }
+    });
   }
 }
 
