@@ -35,6 +35,14 @@ struct ConvBf16Args {
   int ksplit; float* slab;         // fp32 partial sums [ksplit][B*Ho*Wo][N] when ksplit > 1
 };
 
+template <int N_, int I_ = 0, class F>
+__device__ __forceinline__ void bf_static_for(F&& f) {          // f(integral_constant<int, I>) for I = 0 .. N-1, unrolled
+  if constexpr (I_ < N_) {
+    f(std::integral_constant<int, I_>{});
+    bf_static_for<N_, I_ + 1>(f);
+  }
+}
+
 enum { BF_GATHER = 0, BF_PARITY = 1 };
 __device__ __forceinline__ int swz16(int row, int chunk) { return chunk ^ ((row >> 1) & 3); }
 
@@ -99,8 +107,13 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_kernel(ConvBf16Args p) {
   const long shift_px = (MODE == BF_GATHER) ? (2L * p.W + 2) * p.ldx : (1L * p.W + 1) * p.ldx;
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x - shift_px), 0, OOB, 0x00020000);
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wp, 0, OOB, 0x00020000);
-  f32x4 ra[RA], rb[RB];
-  auto load_tile = [&](int kt) {                              // tap outer, channel chunk inner
+  // DEPTH register sets: the request for K-tile kt + DEPTH is issued when K-tile kt starts, so an operand has DEPTH - 1 tile
+  // times to arrive before it is written to LDS -- a bf16 K-tile is 8..16 MFMAs per wave (128..256 cycles), far shorter than an
+  // L2 round trip, and with one tile ahead the loop ran at load latency (2 us per K-tile)
+  constexpr int DEPTH = 3;
+  f32x4 ra[DEPTH][RA], rb[DEPTH][RB];
+  auto load_tile = [&](int kt, auto setc) __attribute__((always_inline)) {      // tap outer, channel chunk inner
+    constexpr int set_ = decltype(setc)::value;
     const int tap = kt / cpt, cc = kt - tap * cpt;
     const int th = (ntw == 5) ? tap / 5 : (ntw == 3) ? tap / 3 : tap >> 1;
     const int tw = tap - th * ntw;
@@ -110,21 +123,22 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_kernel(ConvBf16Args p) {
 #pragma unroll
     for (int r = 0; r < RA; ++r) {
       const unsigned vo = ((a_mask[r] >> tap) & 1u) ? a_voff[r] : OOB;
-      ra[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)vo, soff_a, 0));
+      ra[set_][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)vo, soff_a, 0));
     }
 #pragma unroll
-    for (int r = 0; r < RB; ++r) rb[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (int)b_voff[r], soff_b, 0));
+    for (int r = 0; r < RB; ++r) rb[set_][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (int)b_voff[r], soff_b, 0));
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf, auto setc) __attribute__((always_inline)) {
+    constexpr int set_ = decltype(setc)::value;
 #pragma unroll
     for (int r = 0; r < RA; ++r) {
       const int row = (t >> 2) + 64 * r;
-      if (BM % 64 == 0 || row < BM) *(f32x4*)(&As[buf][row * 16 + swz16(row, chunk) * 4]) = ra[r];
+      if (BM % 64 == 0 || row < BM) *(f32x4*)(&As[buf][row * 16 + swz16(row, chunk) * 4]) = ra[set_][r];
     }
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
       const int row = (t >> 2) + 64 * r;
-      if (BN % 64 == 0 || row < BN) *(f32x4*)(&Bs[buf][row * 16 + swz16(row, chunk) * 4]) = rb[r];
+      if (BN % 64 == 0 || row < BN) *(f32x4*)(&Bs[buf][row * 16 + swz16(row, chunk) * 4]) = rb[set_][r];
     }
   };
   f32x4 acc[TM][TN];
@@ -132,29 +146,35 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_kernel(ConvBf16Args p) {
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  if (kt_begin < kt_end) { load_tile(kt_begin); store_tile(0); }
+  bf_static_for<DEPTH>([&](auto dc) { if (kt_begin + decltype(dc)::value < kt_end) load_tile(kt_begin + decltype(dc)::value, dc); });
+  if (kt_begin < kt_end) store_tile(0, std::integral_constant<int, 0>{});
   __syncthreads();
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    const int buf = (kt - kt_begin) & 1;
-    const bool more = kt + 1 < kt_end;
-    if (more) load_tile(kt + 1);
-    bf16x8 fa[TM], fb[TN];
+  for (int kt = kt_begin; kt < kt_end; kt += DEPTH) {
+    bf_static_for<DEPTH>([&](auto dc) {
+      constexpr int d_ = decltype(dc)::value;
+      const int cur = kt + d_;
+      if (cur < kt_end) {                                     // (block-uniform)
+        const int buf = (cur - kt_begin) & 1;
+        if (cur + DEPTH < kt_end) load_tile(cur + DEPTH, dc);  // set d_ is free: K-tile `cur` went to LDS one step ago
+        bf16x8 fa[TM], fb[TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int row = wm * (TM * 16) + i * 16 + lrow;
-      fa[i] = __builtin_bit_cast(bf16x8, *(const f32x4*)(&As[buf][row * 16 + swz16(row, q) * 4]));
-    }
+        for (int i = 0; i < TM; ++i) {
+          const int row = wm * (TM * 16) + i * 16 + lrow;
+          fa[i] = __builtin_bit_cast(bf16x8, *(const f32x4*)(&As[buf][row * 16 + swz16(row, q) * 4]));
+        }
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int row = wn * (TN * 16) + j * 16 + lrow;
-      fb[j] = __builtin_bit_cast(bf16x8, *(const f32x4*)(&Bs[buf][row * 16 + swz16(row, q) * 4]));
-    }
+        for (int j = 0; j < TN; ++j) {
+          const int row = wn * (TN * 16) + j * 16 + lrow;
+          fb[j] = __builtin_bit_cast(bf16x8, *(const f32x4*)(&Bs[buf][row * 16 + swz16(row, q) * 4]));
+        }
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);   // weights first: see the epilogue
-    if (more) store_tile(buf ^ 1);
-    __syncthreads();
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);   // weights first: see the epilogue
+        if (cur + 1 < kt_end) store_tile(buf ^ 1, std::integral_constant<int, (d_ + 1) % DEPTH>{});
+        __syncthreads();
+      }
+    });
   }
   // epilogue.  The weights are the FIRST MFMA operand, so the D tile is [channel][pixel]: column lane & 15 = GEMM row (pixel),
   // rows 4 (lane >> 4) + reg = four CONSECUTIVE output channels -- one 8-byte bf16 store (or one 16-byte slab store) per lane
@@ -191,13 +211,6 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_kernel(ConvBf16Args p) {
 }
 
 
-template <int N_, int I_ = 0, class F>
-__device__ __forceinline__ void bf_static_for(F&& f) {          // f(integral_constant<int, I>) for I = 0 .. N-1, unrolled
-  if constexpr (I_ < N_) {
-    f(std::integral_constant<int, I_>{});
-    bf_static_for<N_, I_ + 1>(f);
-  }
-}
 
 // ------------------------------------------------------------------------------------------------
 // LDS-window form of the PARITY mode for the shallow decoder layers (deconv4: 128 -> 32, deconv5: 64 -> 16 channels; 2/3 of
@@ -500,19 +513,23 @@ __global__ __launch_bounds__(256) void conv2_window_bf16_kernel(Conv2WinArgs p) 
   for (int j = 0; j < 2; ++j)
 #pragma unroll
     for (int r = 0; r < 4; ++r) sh[j][r] = p.shift[j * 16 + q * 4 + r];
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int ow0 = (tile % tiles_w) * TW, oh0 = ((tile / tiles_w) % tiles_h) * TH;
-    const long b = tile / (tiles_w * tiles_h);
-    const u16* const xb = p.x + b * p.H * p.W * p.ldx;
-    uint4 stage[NST];
+  uint4 stage[NST];
+  auto fetch_window = [&](int tile) __attribute__((always_inline)) {              // global -> registers (in flight during the previous tile's MFMAs)
+    const int fow0 = (tile % tiles_w) * TW, foh0 = ((tile / tiles_w) % tiles_h) * TH;
+    const u16* const xb = p.x + (long)(tile / (tiles_w * tiles_h)) * p.H * p.W * p.ldx;
 #pragma unroll
     for (int k = 0; k < NST; ++k) {
       const int e = t + k * 256, hf = e & 1, px = e >> 1;
       const int wr = px / WC, wc = px - wr * WC;
-      const int ih = 2 * oh0 - 2 + wr, iw = 2 * ow0 - 2 + wc;
+      const int ih = 2 * foh0 - 2 + wr, iw = 2 * fow0 - 2 + wc;
       stage[k] = make_uint4(0u, 0u, 0u, 0u);
       if (e < NCH && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) stage[k] = *(const uint4*)(xb + ((long)ih * p.W + iw) * p.ldx + hf * 8);
     }
+  };
+  if ((int)blockIdx.x < ntiles) fetch_window(blockIdx.x);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int ow0 = (tile % tiles_w) * TW, oh0 = ((tile / tiles_w) % tiles_h) * TH;
+    const long b = tile / (tiles_w * tiles_h);
     __syncthreads();                                                               // the previous tile's readers are done
 #pragma unroll
     for (int k = 0; k < NST; ++k) {
@@ -520,6 +537,7 @@ __global__ __launch_bounds__(256) void conv2_window_bf16_kernel(Conv2WinArgs p) 
       const int wr = px / WC, wc = px - wr * WC;
       if (e < NCH) *(uint4*)(&win[((wr * 2 + (wc & 1)) * PW + (wc >> 1)) * 32 + hf * 16]) = stage[k];
     }
+    if (tile + (int)gridDim.x < ntiles) fetch_window(tile + gridDim.x);
     __syncthreads();
     f32x4 acc[2][2];                                                               // [pixel row i][channel tile j]
 #pragma unroll
@@ -587,55 +605,70 @@ __global__ __launch_bounds__(256) void deconv6_mfma_bf16_kernel(Deconv6Args p) {
   __shared__ __attribute__((aligned(16))) u16 win[NPX * PS];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lrow = lane & 15, q = lane >> 4;
   const int tiles_w = (p.W + TW - 1) / TW, tiles_h = (p.H + TH - 1) / TH;
-  const int tile = blockIdx.x;
-  const int tw0 = (tile % tiles_w) * TW, th0 = ((tile / tiles_w) % tiles_h) * TH;
-  const long b = tile / (tiles_w * tiles_h);
-  const u16* const xb = p.x + b * p.H * p.W * p.ldx;
-#pragma unroll
-  for (int k = 0; k < (NPX * 4 + 255) / 256; ++k) {
-    const int e = t + k * 256, px = e >> 2, cq = e & 3;
-    if (px >= NPX) break;
-    const int lh = px / WW, lw = px - lh * WW;
-    const int ih = th0 - 1 + lh, iw = tw0 - 1 + lw;
-    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-    if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) v = *(const uint4*)(xb + ((long)ih * p.W + iw) * p.ldx + cq * 8);
-    *(uint4*)(&win[px * PS + cq * 8]) = v;
-  }
+  const int ntiles = p.B * tiles_h * tiles_w;
+  constexpr int NST = (NPX * 4 + 255) / 256;
+  // persistent blocks: the nine weight fragments (36 KB per block from L2 -- twice the window) are fetched once, and the next
+  // tile's window is requested before the current tile's MFMAs
   bf16x8 fb[9];
 #pragma unroll
   for (int pos = 0; pos < 9; ++pos) fb[pos] = *(const bf16x8*)(p.w2 + (pos * 16 + lrow) * 32 + q * 8);
-  __syncthreads();
   const float bias = p.bias[0];
   const int ph = (lrow >> 1) & 1, pw = lrow & 1;
+  uint4 stage[NST];
+  auto fetch_window = [&](int tile) __attribute__((always_inline)) {
+    const int ftw0 = (tile % tiles_w) * TW, fth0 = ((tile / tiles_w) % tiles_h) * TH;
+    const u16* const xb = p.x + (long)(tile / (tiles_w * tiles_h)) * p.H * p.W * p.ldx;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int ah = 2 * wave + i;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int pos = 0; pos < 9; ++pos) {
-      const int dh = pos / 3, dw = pos % 3;                      // window coordinates of (anchor - 1 + d)
-      const bf16x8 fa = *(const bf16x8*)(&win[((ah + dh) * WW + lrow + dw) * PS + q * 8]);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[pos], acc, 0, 0, 0);
+    for (int k = 0; k < NST; ++k) {
+      const int e = t + k * 256, px = e >> 2, cq = e & 3;
+      const int lh = px / WW, lw = px - lh * WW;
+      const int ih = fth0 - 1 + lh, iw = ftw0 - 1 + lw;
+      stage[k] = make_uint4(0u, 0u, 0u, 0u);
+      if (px < NPX && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) stage[k] = *(const uint4*)(xb + ((long)ih * p.W + iw) * p.ldx + cq * 8);
     }
-    // C map: column lrow (= parity for lrow < 4), rows q*4 + r = anchors tw0 + q*4 + r
-    float own[4], oth[4];
+  };
+  if ((int)blockIdx.x < ntiles) fetch_window(blockIdx.x);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int tw0 = (tile % tiles_w) * TW, th0 = ((tile / tiles_w) % tiles_h) * TH;
+    const long b = tile / (tiles_w * tiles_h);
+    __syncthreads();                                               // the previous tile's readers are done
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      own[r] = 1.f / (1.f + __expf(-(acc[r] + bias)));
-      oth[r] = __shfl_xor(own[r], 1, 64);
+    for (int k = 0; k < NST; ++k) {
+      const int e = t + k * 256, px = e >> 2, cq = e & 3;
+      if (px < NPX) *(uint4*)(&win[px * PS + cq * 8]) = stage[k];
     }
-    const int oh = 2 * (th0 + ah) + ph;
-    if (lrow >= 4 || th0 + ah >= p.H || oh >= p.Ho) continue;
-    // pw = 0 writes the outputs of anchors q*4, q*4+1 (4 columns), pw = 1 those of anchors q*4+2, q*4+3
-    const int ow0 = 2 * (tw0 + q * 4) + 4 * pw;
-    const float v0 = pw ? oth[2] : own[0], v1 = pw ? own[2] : oth[0], v2 = pw ? oth[3] : own[1], v3 = pw ? own[3] : oth[1];
-    float* dst = p.y + (b * p.Ho + oh) * p.Wo + ow0;
-    if ((p.Wo & 3) == 0 && ow0 + 3 < p.Wo) *(f32x4*)dst = (f32x4){v0, v1, v2, v3};
-    else {
-      if (ow0 < p.Wo) dst[0] = v0;
-      if (ow0 + 1 < p.Wo) dst[1] = v1;
-      if (ow0 + 2 < p.Wo) dst[2] = v2;
-      if (ow0 + 3 < p.Wo) dst[3] = v3;
+    if (tile + (int)gridDim.x < ntiles) fetch_window(tile + gridDim.x);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ah = 2 * wave + i;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int pos = 0; pos < 9; ++pos) {
+        const int dh = pos / 3, dw = pos % 3;                      // window coordinates of (anchor - 1 + d)
+        const bf16x8 fa = *(const bf16x8*)(&win[((ah + dh) * WW + lrow + dw) * PS + q * 8]);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[pos], acc, 0, 0, 0);
+      }
+      // C map: column lrow (= parity for lrow < 4), rows q*4 + r = anchors tw0 + q*4 + r
+      float own[4], oth[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        own[r] = 1.f / (1.f + __expf(-(acc[r] + bias)));
+        oth[r] = __shfl_xor(own[r], 1, 64);
+      }
+      const int oh = 2 * (th0 + ah) + ph;
+      if (lrow >= 4 || th0 + ah >= p.H || oh >= p.Ho) continue;
+      // pw = 0 writes the outputs of anchors q*4, q*4+1 (4 columns), pw = 1 those of anchors q*4+2, q*4+3
+      const int ow0 = 2 * (tw0 + q * 4) + 4 * pw;
+      const float v0 = pw ? oth[2] : own[0], v1 = pw ? own[2] : oth[0], v2 = pw ? oth[3] : own[1], v3 = pw ? own[3] : oth[1];
+      float* dst = p.y + (b * p.Ho + oh) * p.Wo + ow0;
+      if ((p.Wo & 3) == 0 && ow0 + 3 < p.Wo) *(f32x4*)dst = (f32x4){v0, v1, v2, v3};
+      else {
+        if (ow0 < p.Wo) dst[0] = v0;
+        if (ow0 + 1 < p.Wo) dst[1] = v1;
+        if (ow0 + 2 < p.Wo) dst[2] = v2;
+        if (ow0 + 3 < p.Wo) dst[3] = v3;
+      }
     }
   }
 }
@@ -865,7 +898,7 @@ extern "C" int svs_unet_forward_eval_bf16(const void* prepared_bf16, const float
   {
     Deconv6Args d{e.cat[1], 32L, B, e.h[1], e.w[1], (const u16*)(blob + L.w6), (const float*)(blob + L.bias6), mask, H, W};
     const long tiles = (long)B * ((e.h[1] + 7) / 8) * ((e.w[1] + 15) / 16);
-    hipLaunchKernelGGL(deconv6_mfma_bf16_kernel, dim3((unsigned)tiles), dim3(256), 0, stream, d);
+    hipLaunchKernelGGL(deconv6_mfma_bf16_kernel, dim3((unsigned)(tiles < 2048 ? tiles : 2048)), dim3(256), 0, stream, d);
     SVS_CHECK_LAUNCH("deconv6_mfma_bf16");
   }
   return SVS_OK;
