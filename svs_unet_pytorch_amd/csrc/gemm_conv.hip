@@ -721,13 +721,17 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
 // ---- host side ---------------------------------------------------------------------------------
 struct ConvPlan { int cfg; int BM, BN; int ksplit; long mtiles; int grid_y; };
 
-static ConvPlan plan_conv(int mode, long Mmax, int N, int nkt_min, bool narrow = false) {
+// `inference`: the call has the folded-BatchNorm epilogue (eval forward).  Those calls run at the serving batch sizes (1..16
+// tiles, BASELINE configs[0..1]) and take the rules of the batch-16 sweep; the training calls keep the batch-64 table (same-device
+// A/B: the batch-16 rules cost the batch-64 train step 0.6 %, and gain the batch-16 forward 3.6 %).
+static ConvPlan plan_conv(int mode, long Mmax, int N, int nkt_min, bool narrow = false, bool inference = false) {
   ConvPlan pl{};
+  const bool v2 = inference && svs_tune(SVS_TUNE_CONV_PLAN) != 0;
   if (N % 128 == 0) {
     if (Mmax <= 96) { pl.cfg = 4; pl.BM = 32; pl.BN = 128; }
     else { pl.cfg = 0; pl.BM = 128; pl.BN = 128; }
   } else if (N == 64) {
-    if (Mmax <= 512 || nkt_min <= 25) { pl.cfg = 5; pl.BM = 64; pl.BN = 64; }      // (16 input channels: deconv5 backward-data, -9 % in the sweep)
+    if (Mmax <= 512 || nkt_min <= 25 || (v2 && Mmax <= 16384)) { pl.cfg = 5; pl.BM = 64; pl.BN = 64; }      // (16 input channels: deconv5 backward-data, -9 % in the sweep; batch 16: conv3 forward 33 -> 27 us)
     else { pl.cfg = 1; pl.BM = 128; pl.BN = 64; }
   } else if (N == 32) { pl.cfg = 2; pl.BM = 256; pl.BN = 32; }
   else { pl.cfg = 3; pl.BM = 256; pl.BN = 16; }
@@ -738,7 +742,7 @@ static ConvPlan plan_conv(int mode, long Mmax, int N, int nkt_min, bool narrow =
   // skip is exact per position, and 4x the tiles need a quarter of the K-splits (same-device sweep at B=64: 64x64
   // beats 128x128 on every such layer, by 20 % on the 8x2 parity layers).
   if (narrow && N % 64 == 0) { pl.cfg = 5; pl.BM = 64; pl.BN = 64; }
-  if (narrow && N == 128) { pl.cfg = 6; pl.BM = 64; pl.BN = 128; }     // (deconv2 forward -9 %, conv4 fwd / conv5 bwd-data -2 %)
+  if (narrow && N == 128 && !(v2 && Mmax < (mode == MODE_PARITY ? 2048 : 8192))) { pl.cfg = 6; pl.BM = 64; pl.BN = 128; }     // (batch 64: deconv2 forward -9 %, conv4 fwd / conv5 bwd-data -2 %; batch 16: 64x64 is 10-15 % ahead)
   if (svs_tune_on(SVS_TUNE_CONV_CFG)) {      // sweeps only
     static const int bm[7] = {128, 128, 256, 256, 32, 64, 64}, bn[7] = {128, 64, 32, 16, 128, 64, 128};
     const int c = (int)svs_tune(SVS_TUNE_CONV_CFG);
@@ -748,7 +752,7 @@ static ConvPlan plan_conv(int mode, long Mmax, int N, int nkt_min, bool narrow =
   pl.grid_y = (mode == MODE_PARITY) ? 4 : 1;
   const long blocks = pl.mtiles * (N / pl.BN) * pl.grid_y;
   int ks = 1;
-  const long target = (mode == MODE_PARITY) ? 1024 : 768;
+  const long target = (mode == MODE_PARITY) ? 1024 : (v2 ? 512 : 768);     // (batch-16 sweep: two gather blocks per CU beat three on every layer)
   if (blocks < ((mode == MODE_PARITY) ? 768 : 384)) {
     ks = (int)((target + blocks - 1) / blocks);
     // keep >= 8 K-tiles per split (16 in gather mode: with K = 25 or 50 tiles -- conv2 / conv3 at batch 16 -- finer
@@ -856,7 +860,7 @@ int svs_conv_gemm_run(int mode, const float* x, long ldx, int B, int H, int W, i
   // operands are addressed with 32-bit byte offsets (buffer loads): each view must stay below 2 GiB
   SVS_REQUIRE(((long)B * H * W * ldx + 4L * (W + 2) * ldx) * 4 < (1L << 31) && (long)N * C * 25 * 4 < (1L << 31),
               "%s: input view of %ld bytes needs 64-bit offsets; split the batch", who, (long)B * H * W * ldx * 4);
-  ConvPlan pl = plan_conv(mode, Mmax, N, nkt_min, narrow_level(mode, B, C, Wo, N));
+  ConvPlan pl = plan_conv(mode, Mmax, N, nkt_min, narrow_level(mode, B, C, Wo, N), scale != nullptr);
   ConvGemmArgs a{};
   a.x = x; a.ldx = ldx; a.B = B; a.H = H; a.W = W; a.C = C; a.wp = wp;
   a.bias = bias; a.scale = scale; a.shift = shift; a.slope = slope;
@@ -949,9 +953,11 @@ size_t svs_conv_gemm_workspace(int mode, int B, int H, int W, int C, int Ho, int
   int nkt_min;
   if (mode == MODE_GATHER) { Mmax = (long)B * Ho * Wo; nkt_min = 25 * (C / 16); }
   else { Mmax = (long)B * ((Ho + 1) / 2) * ((Wo + 1) / 2); nkt_min = 4 * (C / 16); }
-  ConvPlan pl = plan_conv(mode, Mmax, N, nkt_min, narrow_level(mode, B, C, Wo, N));
-  if (pl.ksplit <= 1) return 0;
-  return (size_t)pl.ksplit * B * Ho * Wo * N * sizeof(float);
+  const int ks_train = plan_conv(mode, Mmax, N, nkt_min, narrow_level(mode, B, C, Wo, N), false).ksplit;
+  const int ks_eval = plan_conv(mode, Mmax, N, nkt_min, narrow_level(mode, B, C, Wo, N), true).ksplit;
+  const int ks = ks_train > ks_eval ? ks_train : ks_eval;          // (one workspace serves either kind of call)
+  if (ks <= 1) return 0;
+  return (size_t)ks * B * Ho * Wo * N * sizeof(float);
 }
 
 // Name (as rocprofv3 prints it) and K-split of the kernel the planner picks for a conv GEMM -- bench.py groups its

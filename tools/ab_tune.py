@@ -20,25 +20,36 @@ ap.add_argument("b", type=int, nargs="?", default=-1)
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--rounds", type=int, default=4)
 ap.add_argument("--steps", type=int, default=30)
+ap.add_argument("--eval", action="store_true", help="time the eval forward instead of the train step")
 args = ap.parse_args()
 B = args.batch
 model = UNet()
 model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in synth.closed_form_state(trained_stats=False).items()})
 model.to("cuda").train()
+if args.eval:
+    model.eval()
 mix = torch.empty((B, 1, 512, 128), device="cuda")
 voc = torch.empty_like(mix)
 _lib.check(_lib.lib().svs_fill_tiles(mix.data_ptr(), voc.data_ptr(), B, 512, 128, 0, _lib.stream_ptr()))
+def one():
+    if args.eval:
+        with torch.no_grad():
+            model(mix)
+    else:
+        model.train_step(mix, voc, loss_scale=ALPHA_L1)
+
+
 res = {args.a: [], args.b: []}
 for r in range(args.rounds):
     for val in (args.a, args.b):
         _lib.tuning(args.name, val)
         for _ in range(5):
-            model.train_step(mix, voc, loss_scale=ALPHA_L1)
+            one()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            model.train_step(mix, voc, loss_scale=ALPHA_L1)
+            one()
         torch.cuda.synchronize()
         res[val].append(1e3 * (time.perf_counter() - t0) / args.steps)
 for val, v in res.items():
-    print(f"{args.name}={val}: median {np.median(v):.4f} ms/step  min {min(v):.4f}  all {[round(x, 4) for x in v]}")
+    print(f"{args.name}={val}: median {np.median(v):.4f} ms  min {min(v):.4f}  all {[round(x, 4) for x in v]}")
