@@ -536,10 +536,10 @@ def test_train_step_full_objective(report):
 def test_eval_forward_bf16(report):
     """BASELINE configs[4]: the bf16-MFMA eval network (bf16 activations and weights, fp32 accumulation) against the fp32
     forward on the same weights -- not a parity gate (activations are rounded to 8 significant bits per layer) but a
-    measured, bounded deviation: mean |mask_bf16 - mask_fp32| and the maximum, at B = 1, 5 and an odd size; and against the
+    measured, bounded deviation: mean |mask_bf16 - mask_fp32| and the maximum, at B = 1, 5 and odd / small sizes; and against the
     fp32 CPU oracle."""
     model = make_model().eval()
-    for B, h, w in ((1, 512, 128), (5, 512, 128), (2, 513, 100)):
+    for B, h, w in ((1, 512, 128), (5, 512, 128), (2, 513, 100), (3, 200, 72), (1, 64, 32), (2, 31, 17)):      # (the small ones take the GEMM form of the window layers)
         x_np = synth.uniform(synth.SEED_MIX, B * h * w, 77 << 32).reshape(B, 1, h, w)
         x = torch.from_numpy(x_np).to(DEV)
         with torch.no_grad():
@@ -549,10 +549,10 @@ def test_eval_forward_bf16(report):
             got = model(x).cpu()
             model.eval_precision = "fp32"
         assert got.shape == want.shape and torch.isfinite(got).all()
-        assert report(f"bf16 eval mask mean |d| vs fp32 (B={B}, {h}x{w})", (got - want).abs().mean().item(), 1e-2)
-        assert report(f"bf16 eval mask max |d| vs fp32 (B={B}, {h}x{w})", (got - want).abs().max().item(), 1e-1)
+        assert report(f"bf16 eval mask mean |d| vs fp32 (B={B}, {h}x{w})", (got - want).abs().mean().item(), 1e-3)
+        assert report(f"bf16 eval mask max |d| vs fp32 (B={B}, {h}x{w})", (got - want).abs().max().item(), 1e-2)
     st = uo.to_torch_state(synth.closed_form_state())
     with torch.no_grad():
         ref = uo.forward(st, torch.from_numpy(x_np[:1]))
-    assert report("bf16 eval mask mean |d| vs fp32 CPU oracle", (got[:1] - ref).abs().mean().item(), 1e-2)
+    assert report("bf16 eval mask mean |d| vs fp32 CPU oracle", (got[:1] - ref).abs().mean().item(), 1e-3)
 
