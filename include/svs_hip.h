@@ -47,8 +47,11 @@ int svs_version(void);
 const char* svs_last_error_string(void);
 /* Planner overrides for sweeps, A/B runs and tests -- never needed in production.  `name` is one of CONV_CFG,
  * CONV_KSPLIT, CONV_WINDOW, CONV_SKIP, CONV_KORDER, CONV_DIRECT, SKIP_REDUCE, WGRAD_CFG, WGRAD_KSPLIT, WGRAD_SKIP,
- * WGRAD_WINDOW, WGRAD_C1_VALU, SIDE_PRIORITY, TRAIN_UNFUSED, TRAIN_ONE_STREAM, or "*" for all; value -1 = planner
- * default.  The table is initialised once from the environment (SVS_<NAME>); no call path reads the environment. */
+ * WGRAD_WINDOW, WGRAD_C1_VALU, SIDE_PRIORITY, TRAIN_UNFUSED, TRAIN_ONE_STREAM, CONV_PLAN (0: batch-64 tile table for the
+ * inference calls too), MFMA_SPLIT (1: the fp32 GEMM kernels form their products on the bf16 MFMA from exact three-limb
+ * splits of the fp32 operands -- fp32-accurate, see csrc/mfma_split.h; default off), or "*" for all; value -1 = planner
+ * default ("*", -1: every switch back to what the environment gave at load).  The table is initialised from the
+ * environment (SVS_<NAME>) at first use; no compute path reads the environment. */
 int svs_tuning_set(const char* name, long value);
 
 /* ---------------------------------------------------------------------------------------------

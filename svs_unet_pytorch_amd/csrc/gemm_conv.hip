@@ -22,6 +22,7 @@
 
 #include <type_traits>
 #include "common.h"
+#include "mfma_split.h"
 
 enum { MODE_GATHER = 0, MODE_PARITY = 1 };
 
@@ -52,7 +53,7 @@ __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >>
 // for all of them at once and its K-tiles are skipped outright (no loads, no MFMAs): -30% work on the 8x2 level,
 // -15% on 16x4.  Skipped products are exact zeros, so results do not change.  Needs tap-outer K order and C/16 a
 // power of two.
-template <int MODE, int BM, int BN, int WM, int WN, bool SKIP = false>
+template <int MODE, int BM, int BN, int WM, int WN, bool SKIP = false, bool SPLIT = false>     // SPLIT: mfma_split.h (optional mode)
 __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs p) {
   constexpr int TM = BM / WM / 16;
   constexpr int TN = BN / WN / 16;
@@ -243,13 +244,23 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs p) {
       const int row = wn * (TN * 16) + j * 16 + lrow;
       fb[j] = *(const f32x4*)(&Bs[buf][row * 16 + swz(row, q) * 4]);
     }
+    if constexpr (SPLIT) {
+      SvsSplitA sa[TM];
+      SvsSplitB sb[TN];
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
+      for (int i = 0; i < TM; ++i) sa[i] = svs_split_a(fa[i][0], fa[i][1], fa[i][2], fa[i][3]);
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int j = 0; j < TN; ++j) sb[j] = svs_split_b(fb[j][0], fb[j][1], fb[j][2], fb[j][3]);
+      svs_mma_split<TM, TN>(acc, sa, sb);
+    } else {
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][k], fb[j][k], acc[i][j], 0, 0, 0);
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][k], fb[j][k], acc[i][j], 0, 0, 0);
+    }
     if (more) store_tile(buf ^ 1);
     __syncthreads();
   }
@@ -768,30 +779,34 @@ static ConvPlan plan_conv(int mode, long Mmax, int N, int nkt_min, bool narrow =
   return pl;
 }
 
-template <int MODE>
-static int launch_conv_gemm(const ConvGemmArgs& a, const ConvPlan& pl, hipStream_t stream, bool skip) {
-  dim3 grid((unsigned)(pl.mtiles * (a.N / pl.BN)), (unsigned)pl.ksplit, (unsigned)pl.grid_y);      // (tiles, K-splits, parity classes)
+template <int MODE, bool SPLIT>
+static void launch_conv_gemm_cfg(const ConvGemmArgs& a, const ConvPlan& pl, dim3 grid, hipStream_t stream, bool skip) {
   dim3 block(256);
   if (skip) {                                // batch-innermost rows + padding-tap skipping (deep levels)
     switch (pl.cfg) {
-      case 0: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 128, 128, 2, 2, true>), grid, block, 0, stream, a); break;
-      case 1: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 128, 64, 2, 2, true>), grid, block, 0, stream, a); break;
-      case 4: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 32, 128, 1, 4, true>), grid, block, 0, stream, a); break;
-      case 6: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 64, 128, 2, 2, true>), grid, block, 0, stream, a); break;
-      default: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 64, 64, 2, 2, true>), grid, block, 0, stream, a); break;
+      case 0: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 128, 128, 2, 2, true, SPLIT>), grid, block, 0, stream, a); break;
+      case 1: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 128, 64, 2, 2, true, SPLIT>), grid, block, 0, stream, a); break;
+      case 4: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 32, 128, 1, 4, true, SPLIT>), grid, block, 0, stream, a); break;
+      case 6: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 64, 128, 2, 2, true, SPLIT>), grid, block, 0, stream, a); break;
+      default: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 64, 64, 2, 2, true, SPLIT>), grid, block, 0, stream, a); break;
     }
-    SVS_CHECK_LAUNCH("conv_gemm");
-    return SVS_OK;
+    return;
   }
   switch (pl.cfg) {
-    case 0: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 128, 128, 2, 2>), grid, block, 0, stream, a); break;
-    case 1: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 128, 64, 2, 2>), grid, block, 0, stream, a); break;
-    case 2: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 256, 32, 4, 1>), grid, block, 0, stream, a); break;
-    case 3: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 256, 16, 4, 1>), grid, block, 0, stream, a); break;
-    case 4: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 32, 128, 1, 4>), grid, block, 0, stream, a); break;
-    case 6: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 64, 128, 2, 2>), grid, block, 0, stream, a); break;
-    default: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 64, 64, 2, 2>), grid, block, 0, stream, a); break;
+    case 0: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 128, 128, 2, 2, false, SPLIT>), grid, block, 0, stream, a); break;
+    case 1: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 128, 64, 2, 2, false, SPLIT>), grid, block, 0, stream, a); break;
+    case 2: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 256, 32, 4, 1, false, SPLIT>), grid, block, 0, stream, a); break;
+    case 3: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 256, 16, 4, 1, false, SPLIT>), grid, block, 0, stream, a); break;
+    case 4: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 32, 128, 1, 4, false, SPLIT>), grid, block, 0, stream, a); break;
+    case 6: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 64, 128, 2, 2, false, SPLIT>), grid, block, 0, stream, a); break;
+    default: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 64, 64, 2, 2, false, SPLIT>), grid, block, 0, stream, a); break;
   }
+}
+template <int MODE>
+static int launch_conv_gemm(const ConvGemmArgs& a, const ConvPlan& pl, hipStream_t stream, bool skip) {
+  dim3 grid((unsigned)(pl.mtiles * (a.N / pl.BN)), (unsigned)pl.ksplit, (unsigned)pl.grid_y);      // (tiles, K-splits, parity classes)
+  if (svs_tune(SVS_TUNE_MFMA_SPLIT) > 0) launch_conv_gemm_cfg<MODE, true>(a, pl, grid, stream, skip);     // optional mode: mfma_split.h
+  else launch_conv_gemm_cfg<MODE, false>(a, pl, grid, stream, skip);
   SVS_CHECK_LAUNCH("conv_gemm");
   return SVS_OK;
 }

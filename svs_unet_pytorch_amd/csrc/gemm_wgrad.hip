@@ -16,6 +16,7 @@
 #include <stdlib.h>
 
 #include "internal.h"
+#include "mfma_split.h"
 
 struct WgradArgs {
   const float* s; long lds; int Hs, Ws, Cs;
@@ -42,7 +43,7 @@ template <> __device__ __forceinline__ void store_vec<2>(float* p, const float (
 // the 16 pixels of a K-tile are the SAME position (i, j) of 16 images.  A tap that falls into the zero padding at
 // that position does so for the whole tile; a K-tile none of whose N-tile taps is inside the image is skipped
 // outright (about a third of the tiles on the 8x2 level).  The per-tile pixel decode also becomes scalar.
-template <int BM, int BN, int WM, int WN, bool SKIP = false>
+template <int BM, int BN, int WM, int WN, bool SKIP = false, bool SPLIT = false>     // SPLIT: mfma_split.h (optional mode)
 __global__ __launch_bounds__(256) void wgrad_gemm_kernel(WgradArgs p) {
   constexpr int TM = BM / WM / 16;
   constexpr int TN = BN / WN / 16;
@@ -223,6 +224,22 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(WgradArgs p) {
     const bool more = pkn < (int)p_end;
     if (more) { if (SKIP) load_tile_skip(pkn); else load_tile(pkn); }
     pk = pkn;
+    if constexpr (SPLIT) {                     // the lane's four k of every tile row / column, split into bf16 limbs
+      float ga[4][TM], gb[4][TN];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int kr = 4 * q + k;
+        load_vec<TM>(&As[buf][kr * LDA + wm * (TM * 16) + TM * lrow], ga[k]);
+        load_vec<TN>(&Bs[buf][kr * LDB + wn * (TN * 16) + TN * lrow], gb[k]);
+      }
+      SvsSplitA sa[TM];
+      SvsSplitB sb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) sa[i] = svs_split_a(ga[0][i], ga[1][i], ga[2][i], ga[3][i]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) sb[j] = svs_split_b(gb[0][j], gb[1][j], gb[2][j], gb[3][j]);
+      svs_mma_split<TM, TN>(acc, sa, sb);
+    } else {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       // Interleaved tiles: MFMA tile i of this wave owns the rows {TM*r + i : r = 0..15} (and tile j the columns
@@ -237,6 +254,7 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(WgradArgs p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
     }
     if (more) store_tile(buf ^ 1);
     __syncthreads();
@@ -524,16 +542,19 @@ int svs_wgrad_gemm_run(const float* s, long lds, int B, int Hs, int Ws, int Cs, 
               "%s: operand views need 64-bit offsets; split the batch", who);
   dim3 grid((unsigned)(Cs / pl.BM), (unsigned)((25 * Cl + pl.BN - 1) / pl.BN), (unsigned)pl.ksplit);
   const int skip = use_wgrad_skip(B, Hs, Ws, Cl, lds, pl.cfg);
-  if (skip) {
-    a.b_shift = log2_or_neg(B);
-    if (pl.cfg == 0) hipLaunchKernelGGL((wgrad_gemm_kernel<128, 128, 2, 2, true>), grid, dim3(256), 0, stream, a);
-    else if (pl.cfg == 1) hipLaunchKernelGGL((wgrad_gemm_kernel<64, 128, 1, 4, true>), grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((wgrad_gemm_kernel<32, 128, 1, 4, true>), grid, dim3(256), 0, stream, a);
-  } else switch (pl.cfg) {
-    case 0: hipLaunchKernelGGL((wgrad_gemm_kernel<128, 128, 2, 2>), grid, dim3(256), 0, stream, a); break;
-    case 1: hipLaunchKernelGGL((wgrad_gemm_kernel<64, 128, 1, 4>), grid, dim3(256), 0, stream, a); break;
-    default: hipLaunchKernelGGL((wgrad_gemm_kernel<32, 128, 1, 4>), grid, dim3(256), 0, stream, a); break;
+  if (skip) a.b_shift = log2_or_neg(B);
+#define SVS_WGRAD_LAUNCH(SPLIT_) \
+  if (skip) { \
+    if (pl.cfg == 0) hipLaunchKernelGGL((wgrad_gemm_kernel<128, 128, 2, 2, true, SPLIT_>), grid, dim3(256), 0, stream, a); \
+    else if (pl.cfg == 1) hipLaunchKernelGGL((wgrad_gemm_kernel<64, 128, 1, 4, true, SPLIT_>), grid, dim3(256), 0, stream, a); \
+    else hipLaunchKernelGGL((wgrad_gemm_kernel<32, 128, 1, 4, true, SPLIT_>), grid, dim3(256), 0, stream, a); \
+  } else switch (pl.cfg) { \
+    case 0: hipLaunchKernelGGL((wgrad_gemm_kernel<128, 128, 2, 2, false, SPLIT_>), grid, dim3(256), 0, stream, a); break; \
+    case 1: hipLaunchKernelGGL((wgrad_gemm_kernel<64, 128, 1, 4, false, SPLIT_>), grid, dim3(256), 0, stream, a); break; \
+    default: hipLaunchKernelGGL((wgrad_gemm_kernel<32, 128, 1, 4, false, SPLIT_>), grid, dim3(256), 0, stream, a); break; \
   }
+  if (svs_tune(SVS_TUNE_MFMA_SPLIT) > 0) { SVS_WGRAD_LAUNCH(true) } else { SVS_WGRAD_LAUNCH(false) }      // optional mode: mfma_split.h
+#undef SVS_WGRAD_LAUNCH
   SVS_CHECK_LAUNCH("wgrad_gemm");
   if (svs_tune_on(SVS_TUNE_SKIP_REDUCE)) return SVS_OK;             // lets bench.py time the GEMM kernel alone
   return wgrad_reduce_run((const float*)ws, pl.ksplit, Cs, Cl, dw, (float*)ws + (size_t)pl.ksplit * Cs * 25 * Cl, stream);

@@ -36,7 +36,7 @@ extern "C" const char* svs_last_error_string(void) { return g_err; }
 // ---------------------------------------------------------------------------------------------
 static const char* const TUNE_NAMES[SVS_TUNE_COUNT] = {
     "CONV_CFG", "CONV_KSPLIT", "CONV_WINDOW", "CONV_SKIP", "CONV_KORDER", "CONV_DIRECT", "SKIP_REDUCE", "WGRAD_CFG",
-    "WGRAD_KSPLIT", "WGRAD_SKIP", "WGRAD_WINDOW", "WGRAD_C1_VALU", "SIDE_PRIORITY", "TRAIN_UNFUSED", "TRAIN_ONE_STREAM", "CONV_PLAN"};
+    "WGRAD_KSPLIT", "WGRAD_SKIP", "WGRAD_WINDOW", "WGRAD_C1_VALU", "SIDE_PRIORITY", "TRAIN_UNFUSED", "TRAIN_ONE_STREAM", "CONV_PLAN", "MFMA_SPLIT"};
 static long g_tune[SVS_TUNE_COUNT];
 static std::once_flag g_tune_once;
 static void tune_load_env() {
@@ -54,7 +54,11 @@ long svs_tune(int key) {
 extern "C" int svs_tuning_set(const char* name, long value) {
   std::call_once(g_tune_once, tune_load_env);
   SVS_REQUIRE(name, "svs_tuning_set: null name");
-  if (!strcmp(name, "*")) { for (int k = 0; k < SVS_TUNE_COUNT; ++k) g_tune[k] = value; return SVS_OK; }
+  if (!strcmp(name, "*")) {                 // every switch: value -1 = back to the process defaults (the SVS_<NAME> environment)
+    if (value == -1) tune_load_env();
+    else for (int k = 0; k < SVS_TUNE_COUNT; ++k) g_tune[k] = value;
+    return SVS_OK;
+  }
   for (int k = 0; k < SVS_TUNE_COUNT; ++k)
     if (!strcmp(name, TUNE_NAMES[k])) { g_tune[k] = value; return SVS_OK; }
   svs_set_error("svs_tuning_set: unknown switch '%s'", name);
