@@ -216,6 +216,32 @@ def cpu_baseline(mode, seconds_budget=24.0):
             "cases": cases}
 
 
+def split_mode_record(model, dev, B=64, steps=20, warmup=5):
+    """The train step again with the OPTIONAL split-bf16 product mode of the GEMM kernels (csrc/mfma_split.h, DESIGN.md section 5;
+    off by default and not what `value` measures): fp32 operands, products formed from exact three-limb bf16 splits on the
+    bf16 MFMA, fp32 accumulation."""
+    H, W = 512, 128
+    mix = torch.empty((B, 1, H, W), device=dev)
+    voc = torch.empty_like(mix)
+    _lib.check(_lib.lib().svs_fill_tiles(mix.data_ptr(), voc.data_ptr(), B, H, W, 30_000, _lib.stream_ptr()), "svs_fill_tiles")
+    model.train()
+    out = {}
+    for name, val in (("default", -1), ("mfma_split", 1)):
+        _lib.tuning("MFMA_SPLIT", val)
+        for _ in range(warmup):
+            model.train_step(mix, voc, loss_scale=ALPHA_L1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            model.train_step(mix, voc, loss_scale=ALPHA_L1)
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / steps
+        out[name] = {"ms_per_step": round(ms, 4), "tiles_per_s": round(B / ms * 1e3, 1)}
+    _lib.tuning("MFMA_SPLIT", -1)
+    out["note"] = "same process, same device, back to back; `value` above is the default mode"
+    return out
+
+
 def eval_record(model, dev, B=16, steps=30, warmup=5):
     """BASELINE configs[1]: eval forward at B = 16, eager and replayed from a hipGraph (the forward is one graph of 12
     launches; the replay removes the host launch cost that an eager B=16 forward is bound by)."""
@@ -431,6 +457,7 @@ def main():
                                         "in_image": round(fr, 3)} for name, kernel, ks, ms, gf, fr in calls}
             if not args.no_extras:
                 if args.mode == "train":
+                    res["optional_mfma_split"] = split_mode_record(model, dev, B)
                     res["eval_b16"] = eval_record(model, dev)                  # BASELINE configs[1]
                 try:
                     sys.path.insert(0, os.path.join(ROOT, "tools"))
