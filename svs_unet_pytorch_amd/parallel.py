@@ -57,6 +57,19 @@ def broadcast_parameters(model, src: int = 0, group=None):
     model._param_epoch += 1
 
 
+def average_bn_buffers(model, group=None):
+    """BatchNorm running statistics under data parallelism: every rank normalises with its OWN batch statistics (what
+    DistributedDataParallel over the reference would do) and so accumulates its own running mean / variance; before they are
+    used or saved (validation, checkpoint) the ranks take the mean of the per-rank buffers -- one all-reduce of 2 x 1,008
+    floats.  `num_batches_tracked` is the same on every rank already."""
+    world = dist.get_world_size(group)
+    if world == 1:
+        return
+    dist.all_reduce(model._bn_flat, op=dist.ReduceOp.SUM, group=group)
+    model._bn_flat.mul_(1.0 / world)
+    model._param_epoch += 1
+
+
 def init_process_group(rank: int, world: int, device: torch.device):
     """RCCL process group with its collectives on a HIGH-priority stream: the gradient exchange runs beside two saturated
     compute streams (the backward's own and the library's weight-gradient stream, itself high priority) and must not wait

@@ -308,6 +308,9 @@ def main(argv=None):
         avg_train_loss = float(loss_sum) / max(steps, 1)
         log_buffer.append(f"{avg_train_loss}\n")
 
+        if world > 1:                                                      # one set of running statistics for validation / checkpoints
+            from .parallel import average_bn_buffers
+            average_bn_buffers(model)
         if valid_loader and (ep + 1) % args.val_interval == 0:             # train.py:317-363
             model.eval()
             val_sum = 0.0

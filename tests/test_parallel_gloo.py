@@ -15,7 +15,7 @@ import torch.multiprocessing as mp
 from oracle import unet_oracle as uo
 from svs_unet_pytorch_amd import synth
 from svs_unet_pytorch_amd.model import UNet
-from svs_unet_pytorch_amd.parallel import GradAllReduce, broadcast_parameters, shard_range
+from svs_unet_pytorch_amd.parallel import GradAllReduce, average_bn_buffers, broadcast_parameters, shard_range
 
 H, W, B_PER_RANK = 64, 16, 2
 
@@ -57,6 +57,11 @@ def _worker(rank, world, port, out):
         handles = [sync.reduce_async(model._gflat[split:]), sync.reduce_async(model._gflat[:split])]
         for h in handles:
             h.wait()
+        # running statistics: every rank accumulates its own; before use they are averaged over the ranks
+        model._bn_flat.fill_(float(rank + 1))
+        epoch = model._param_epoch
+        average_bn_buffers(model)
+        assert model._param_epoch == epoch + 1 and torch.all(model._bn_flat == 1.5)
         if rank == 0:
             out["flat"] = model._flat.clone()
             out["summed"] = model._gflat.clone()
