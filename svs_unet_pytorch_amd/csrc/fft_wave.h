@@ -119,13 +119,27 @@ struct FftPass {
 // Forward DFT of the N points in `buf` (logical order, padded index), in place, by the calling wave.
 // tw: FftSize<N>::TW entries built with fft_build_twiddles.  The caller orders its own LDS accesses around the call
 // (same wave: program order suffices; other waves must not touch this buffer).
+// Between a pass's stores and the next pass's loads (lanes read what OTHER lanes wrote) the hardware needs nothing -- the LDS
+// operations of one wave execute in program order -- but the compiler must not move a load above a store it can prove
+// independent for the single thread: a wave-level scheduling barrier (no instruction) pins the order.
+//
+// NOTE for every file that includes this header: build it with -fno-slp-vectorize (svs_unet_pytorch_amd/build.py).  The SLP
+// vectoriser turns complex multiplies into packed-fp32 instructions with op_sel swizzles, and on gfx950 a v_pk_{add,mul,fma}_f32
+// whose op_sel takes the HIGH half of a source for the low result returns garbage while a bf16 MFMA of any other wave is
+// executing on the CU (whole frames of garbage as soon as another stream or process ran the bf16 network; tools/stress_victims.py,
+// tools/check_isa.py).  Without the packed forms the transforms are also 5-10 % faster.
+__device__ __forceinline__ void fft_wave_sync() { __builtin_amdgcn_wave_barrier(); }
 template <int N>
 __device__ __forceinline__ void fft_wave(float2* buf, const float2* tw, int lane) {
   using P = FftPlan<N>;
   using S = FftSize<N>;
+  fft_wave_sync();                           // the caller's fill
   { FftPass<N, P::R0, 1> p; p.load(buf, lane); p.compute(nullptr, lane); p.store(buf, lane); }
+  fft_wave_sync();
   { FftPass<N, P::R1, S::NS1> p; p.load(buf, lane); p.compute(tw, lane); p.store(buf, lane); }
+  fft_wave_sync();
   { FftPass<N, P::R2, S::NS2> p; p.load(buf, lane); p.compute(tw + S::TW1, lane); p.store(buf, lane); }
+  fft_wave_sync();                           // before the caller reads other lanes' outputs
 }
 template <int N>
 __device__ __forceinline__ void fft_build_twiddles(float2* tw, int tid, int nthreads) {
