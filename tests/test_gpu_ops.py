@@ -132,6 +132,63 @@ def test_enc_block_fwd(B, H, W, C, N, rows, report, tune):
     assert report(f"enc_fwd acc B{B} {H}x{W} C{C} N{N}", e, 2e-5)
 
 
+@pytest.mark.parametrize("kind,B,H,W,C,N", [("conv", 4, 32, 16, 128, 256), ("conv", 2, 64, 32, 32, 64), ("deconv", 4, 8, 4, 512, 128), ("wgrad", 8, 16, 8, 128, 256)])
+def test_mfma_split_mode_accuracy(kind, B, H, W, C, N, report, tune):
+    """The optional product mode of the GEMM kernels (csrc/mfma_split.h: fp32 operands split exactly into three bf16 limbs, six
+    limb products on the bf16 MFMA, fp32 accumulation) against float64, beside the default fp32-MFMA kernels on the same
+    operands -- operands with four decades of dynamic range, error relative to sum |a b| (the scale of a dot product's
+    rounding error).  The mode must be at least as accurate as the fp32 MFMA (measured: slightly better)."""
+    g = torch.Generator().manual_seed(7)
+    spread = lambda shape: (torch.rand(shape, generator=g) - 0.5) * torch.exp(4.0 * (torch.rand(shape, generator=g) - 0.5))
+    errs = {}
+    if kind == "conv":
+        x, w = spread((B, C, H, W)), spread((N, C, 5, 5)) * 0.1
+        want = F.conv2d(x.double(), w.double(), None, stride=2, padding=2)
+        mag = F.conv2d(x.double().abs(), w.double().abs(), None, stride=2, padding=2)
+        xd, wp = nhwc(x).to(DEV), pack_gather(w)
+        Ho, Wo = (H + 1) // 2, (W + 1) // 2
+        ws = ws_tensor(L().svs_enc_block_workspace_bytes(B, H, W, C, N))
+        for mode in (-1, 1):
+            tune("MFMA_SPLIT", mode)
+            y = torch.empty((B, Ho, Wo, N), device=DEV)
+            _lib.check(L().svs_enc_block_fwd(xd.data_ptr(), C, B, H, W, C, wp.data_ptr(), None, None, None, 0.0, y.data_ptr(), N, N, 0,
+                                             ws.data_ptr(), ws.numel(), S()))
+            errs[mode] = ((nchw(y).cpu().double() - want).abs() / mag)
+    elif kind == "deconv":
+        x, w = spread((B, C, H, W)), spread((C, N, 5, 5)) * 0.1
+        want = F.conv_transpose2d(x.double(), w.double(), None, stride=2, padding=2, output_padding=1)
+        mag = F.conv_transpose2d(x.double().abs(), w.double().abs(), None, stride=2, padding=2, output_padding=1)
+        xd, wp = nhwc(x).to(DEV), pack_parity(w)
+        ws = ws_tensor(L().svs_dec_block_workspace_bytes(B, H, W, C, 2 * H, 2 * W, N))
+        for mode in (-1, 1):
+            tune("MFMA_SPLIT", mode)
+            y = torch.empty((B, 2 * H, 2 * W, N), device=DEV)
+            _lib.check(L().svs_dec_block_fwd(xd.data_ptr(), C, B, H, W, C, wp.data_ptr(), None, None, None, 0.0, y.data_ptr(), N, 2 * H, 2 * W, N, 0,
+                                             ws.data_ptr(), ws.numel(), S()))
+            errs[mode] = ((nchw(y).cpu().double() - want).abs() / mag)
+    else:                                                        # weight gradient of an encoder block: S = output side (N), L = input side (C)
+        dy, x = spread((B, N, H, W)), spread((B, C, 2 * H, 2 * W))
+        xq = x.double().requires_grad_(False)
+        wz = torch.zeros((N, C, 5, 5), dtype=torch.float64, requires_grad=True)
+        F.conv2d(xq, wz, None, stride=2, padding=2).backward(dy.double())
+        want = wz.grad
+        wa = torch.zeros((N, C, 5, 5), dtype=torch.float64, requires_grad=True)
+        F.conv2d(xq.abs(), wa, None, stride=2, padding=2).backward(dy.double().abs())
+        mag = wa.grad
+        sd, ld = nhwc(dy).to(DEV), nhwc(x).to(DEV)
+        ws = ws_tensor(L().svs_block_bwd_weight_workspace_bytes(B, H, W, N, C))
+        for mode in (-1, 1):
+            tune("MFMA_SPLIT", mode)
+            dw = torch.empty(N * C * 25, device=DEV)
+            _lib.check(L().svs_enc_block_bwd_weight(sd.data_ptr(), N, B, H, W, N, ld.data_ptr(), C, 2 * H, 2 * W, C, dw.data_ptr(), None,
+                                                    ws.data_ptr(), ws.numel(), S()))
+            errs[mode] = ((dw.view(N, C, 5, 5).cpu().double() - want).abs() / mag)
+    e32, esp = errs[-1], errs[1]
+    assert report(f"fp32 MFMA      {kind} B{B} {H}x{W} C{C} N{N}: max err / sum|ab|", e32.max().item(), 6e-7)
+    assert report(f"split-bf16 mode {kind} B{B} {H}x{W} C{C} N{N}: max err / sum|ab|", esp.max().item(), 6e-7)
+    assert report(f"split-bf16 mean error relative to the fp32 MFMA's ({kind} C{C} N{N})", (esp.mean() / e32.mean()).item(), 1.1)
+
+
 def test_enc_block_fwd_c1(report):
     for (B, H, W, N) in ((2, 64, 32, 16), (1, 33, 17, 16), (2, 32, 32, 32)):
         x = rnd((B, 1, H, W), 20, 0, 1)
