@@ -754,6 +754,16 @@ static ConvPlan plan_conv(int mode, long Mmax, int N, int nkt_min, bool narrow =
   // beats 128x128 on every such layer, by 20 % on the 8x2 parity layers).
   if (narrow && N % 64 == 0) { pl.cfg = 5; pl.BM = 64; pl.BN = 64; }
   if (narrow && N == 128 && !(v2 && Mmax < (mode == MODE_PARITY ? 2048 : 8192))) { pl.cfg = 6; pl.BM = 64; pl.BN = 128; }     // (batch 64: deconv2 forward -9 %, conv4 fwd / conv5 bwd-data -2 %; batch 16: 64x64 is 10-15 % ahead)
+  // Optional split-bf16 product mode (mfma_split.h): the MFMA part of a K-tile is 2.7x shorter, the per-fragment limb split is
+  // paid once per (row tile + column tile) of a wave, so LARGER wave tiles win (batch-64 sweep in that mode: 128x128 / 64x128
+  // ahead of 64x64 by 8-30 % on every N >= 128 layer, 128x64 on the N = 64 ones), at two blocks per CU
+  const bool split = svs_tune(SVS_TUNE_MFMA_SPLIT) > 0 && svs_tune(SVS_TUNE_CONV_PLAN) != 0;
+  if (split && Mmax > 96) {
+    if (N % 128 == 0) {
+      if (mode == MODE_GATHER && Mmax >= 4096) { pl.cfg = 0; pl.BM = 128; pl.BN = 128; }
+      else { pl.cfg = 6; pl.BM = 64; pl.BN = 128; }
+    } else if (N == 64 && Mmax >= 16384) { pl.cfg = 1; pl.BM = 128; pl.BN = 64; }
+  }
   if (svs_tune_on(SVS_TUNE_CONV_CFG)) {      // sweeps only
     static const int bm[7] = {128, 128, 256, 256, 32, 64, 64}, bn[7] = {128, 64, 32, 16, 128, 64, 128};
     const int c = (int)svs_tune(SVS_TUNE_CONV_CFG);
@@ -763,7 +773,7 @@ static ConvPlan plan_conv(int mode, long Mmax, int N, int nkt_min, bool narrow =
   pl.grid_y = (mode == MODE_PARITY) ? 4 : 1;
   const long blocks = pl.mtiles * (N / pl.BN) * pl.grid_y;
   int ks = 1;
-  const long target = (mode == MODE_PARITY) ? 1024 : (v2 ? 512 : 768);     // (batch-16 sweep: two gather blocks per CU beat three on every layer)
+  const long target = (mode == MODE_PARITY) ? 1024 : ((v2 || split) ? 512 : 768);     // (batch-16 sweep: two gather blocks per CU beat three on every layer)
   if (blocks < ((mode == MODE_PARITY) ? 768 : 384)) {
     ks = (int)((target + blocks - 1) / blocks);
     // keep >= 8 K-tiles per split (16 in gather mode: with K = 25 or 50 tiles -- conv2 / conv3 at batch 16 -- finer
