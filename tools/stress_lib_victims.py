@@ -32,7 +32,25 @@ def v_mr_value():
     return [loss]
 def v_adam_like():
     return [torch.sqrt(xt.abs() + 1.0).sum(dim=(1, 2, 3))]
-victims = [("stft_tiles", v_stft), ("istft_tiles", v_istft), ("eval forward fp32", v_eval), ("MR-STFT value", v_mr_value), ("torch sqrt+sum", v_adam_like)]
+tmodel = UNet(); tmodel.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in synth.closed_form_state(trained_stats=False).items()}); tmodel.to("cuda").train()
+tmix = torch.rand((16, 1, 512, 128), device="cuda"); tvoc = tmix * 0.5
+tmasks = [torch.from_numpy(m) for m in synth.dropout_masks(16, seed=5, step=0)]
+def v_train():
+    tmodel.set_dropout_masks(tmasks)
+    tmodel.optim.zero_grad()
+    loss = tmodel.fwd_bwd(tmix, tvoc, loss_scale=166.66)
+    return [tmodel._gflat, loss]
+def v_train_split():
+    _lib.tuning("MFMA_SPLIT", 1)
+    out = [t.clone() for t in v_train()]
+    _lib.tuning("MFMA_SPLIT", -1)
+    return out
+def v_bf16():
+    model.eval_precision = "bf16"
+    with torch.no_grad(): out = [model(xt)]
+    model.eval_precision = "fp32"
+    return out
+victims = [("train step fp32 (grads)", v_train), ("train step split mode", v_train_split), ("bf16 network forward", v_bf16), ("stft_tiles", v_stft), ("istft_tiles", v_istft), ("eval forward fp32", v_eval), ("MR-STFT value", v_mr_value), ("torch sqrt+sum", v_adam_like)]
 for bg_kind, bg_name in ((None, "nothing"), (1, "fp32 MFMA"), (0, "bf16 MFMA")):
     stop = False
     def background():
