@@ -352,13 +352,13 @@ __global__ __launch_bounds__(512, 2) void istft_kernel(IstftArgs p, int ngroups)
     // the signal, the envelope) are computed once per thread, and which frames exist is uniform across the block per hop.
     float* const yc = p.y + (long)c * p.n_out + ((long)p.hop * t0 - NFFT / 2);
     const long ilo = NFFT / 2 - (long)p.hop * t0, ihi = p.n_out + ilo;       // valid e: ilo <= e < ihi
-    for (int m = tid; m < p.hop; m += 512) {
+    auto emit = [&](int m, int fh_lo, int fh_hi) __attribute__((always_inline)) {
       const bool two = m + p.hop < NFFT;                    // frame fh - 1 still covers this position
       const float w1 = hann_fast(m) * (1.0f / NFFT), w0 = two ? hann_fast(m + p.hop) * (1.0f / NFFT) : 0.f;
       const float e1 = w1 * w1 * (float)(NFFT * NFFT), e0 = w0 * w0 * (float)(NFFT * NFFT);
       const int a1 = fft_pad(m), a0 = fft_pad(two ? m + p.hop : 0);
-#pragma unroll 5
-      for (int fh = 1; fh <= IGROUP; ++fh) {
+#pragma unroll 4
+      for (int fh = fh_lo; fh <= fh_hi; ++fh) {
         const int e = (fh - 1) * p.hop + m;
         if (e < ilo || e >= ihi) continue;
         const int th = t0 - 1 + fh;                         // global index of local frame fh; fh - 1 is th - 1
@@ -368,6 +368,19 @@ __global__ __launch_bounds__(512, 2) void istft_kernel(IstftArgs p, int ngroups)
         const float v = env > 1.1754944e-38f ? s * __builtin_amdgcn_rcpf(env) : s;
         yc[e] = v;
         vmax = fmaxf(vmax, fabsf(v));
+      }
+    };
+    // positions 0 .. 511: one per thread, all 15 hops.  The remaining hop - 512 positions (256 at hop 768) would leave half
+    // the block idle for a second full pass: instead position 512 + j is shared by threads j and j + hop - 512 (if it exists),
+    // which take the lower and the upper half of the hops
+    if (tid < p.hop) emit(tid, 1, IGROUP);
+    const int rest = p.hop - 512;
+    if (rest > 0) {
+      if (2 * rest <= 512) {
+        if (tid < rest) emit(512 + tid, 1, (IGROUP + 1) / 2);
+        else if (tid < 2 * rest) emit(512 + tid - rest, (IGROUP + 1) / 2 + 1, IGROUP);
+      } else {
+        for (int m = 512 + tid; m < p.hop; m += 512) emit(m, 1, IGROUP);
       }
     }
   }
