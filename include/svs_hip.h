@@ -20,7 +20,7 @@
  *   - callable from any host thread and on any stream (torch's autograd engine calls from its own thread): the
  *     per-block and whole-network eval entry points are fully re-entrant; the svs_unet_train_* entry points of one
  *     DEVICE are serialised by a library mutex while they enqueue (they share that device's side stream), and a split
- *     pass (svs_unet_train_fwd_loss, then svs_unet_train_bwd_part 0, 2, 3 or 0, 1) must be issued in order by one
+ *     pass (svs_unet_train_fwd_loss, then svs_unet_train_bwd_part 0, 2, 5, 6 / 0, 2, 3 / 0, 1 / 4) must be issued in order by one
  *     caller at a time;
  *   - the device is the one the `stream` argument belongs to; the caller makes it current (hipSetDevice /
  *     torch.cuda.device) around the call.
@@ -229,9 +229,11 @@ int svs_unet_train_backward(const float* params, float* grads, const float* mix,
 /* Split form for overlapping the data-parallel gradient exchange with the backward pass: forward + loss, then
  * backward part 0 (decoder half: gradients of parameter tensors 24..45, i.e. grads[svs_unet_param_offset(24)..))
  * and part 1 (encoder half: tensors 0..23), or the encoder in two pieces: part 2 (the conv6 block, tensors 20..23 --
- * 13 of the encoder's 17.5 MB) then part 3 (tensors 0..19).  The caller starts the all-reduce of a piece on a second
+ * 13 of the encoder's 17.5 MB) then part 3 (tensors 0..19) -- or part 3 itself as part 5 (conv5 + conv4 blocks, tensors
+ * 12..19, 4.1 MB) then part 6 (conv3..conv1, tensors 0..11, 0.26 MB: all that is left to exchange once the backward has
+ * ended).  Part 4 is the whole backward in one call.  The caller starts the all-reduce of a piece on a second
  * stream as soon as the part is enqueued.  Same results as svs_unet_train_fwd_bwd.
- * Weight gradients are computed on a library-owned side stream.  The call that ends the pass (part 1 or 3) makes
+ * Weight gradients are computed on a library-owned side stream.  The call that ends the pass (part 1, 3, 4 or 6) makes
  * `stream` wait for all of them; after an earlier part, svs_unet_train_bwd_sync(s) makes stream `s` (the one the
  * exchange is issued from) wait for the side-stream work enqueued so far WITHOUT stalling the backward's own stream
  * (`s` must also wait for `stream` itself, e.g. with an event).  The parts of one pass must be issued in order from one

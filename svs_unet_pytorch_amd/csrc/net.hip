@@ -573,7 +573,7 @@ static int train_forward_impl(const ParamView& v, float* bn_buffers, int64_t* nb
 //        bit 1 = encoder half (conv6..conv1: tensors 0..23).  A data-parallel caller runs them as two calls and
 //        all-reduces the decoder half of the flat gradient buffer while the encoder half is still being computed.
 static int train_backward_impl(const ParamView& v, float* grads, const float* mix, const float* drop, const Geo& g,
-                               const TrainWs& t, hipStream_t stream, int parts = 7) {
+                               const TrainWs& t, hipStream_t stream, int parts = 15) {
   const int B = g.B;
   int rc;
   auto G = [&](int idx) { return grads + svs_unet_param_offset(idx); };
@@ -640,10 +640,11 @@ static int train_backward_impl(const ParamView& v, float* grads, const float* mi
   if ((rc = svs_channel_sum_finalize_multi_run(sums, stream))) return rc;    // the five decoder bias gradients
   sums.njobs = 0;
   }
-  if (!(parts & 6)) return SVS_OK;
-  // encoders 6..1 (bit 2: block 6, whose 13 MB of gradients are most of the encoder's; bit 4: blocks 5..1)
+  if (!(parts & 14)) return SVS_OK;
+  // encoders 6..1 (bit 2: block 6, whose 13 MB of gradients are most of the encoder's; bit 4: blocks 5 and 4 (4.1 MB);
+  // bit 8: blocks 3..1 (0.26 MB: the only piece a data-parallel step exchanges after the backward has ended))
   for (int k = 6; k >= 1; --k) {
-    if (!(parts & (k == 6 ? 2 : 4))) continue;
+    if (!(parts & (k == 6 ? 2 : k >= 4 ? 4 : 8))) continue;
     const int l = k - 1, N = CH[k], C = CH[k - 1];
     const View dyv = (k == 6) ? View{t.dc6, 512} : cat_half(t.dcat, g, k, 1);
     const float* dy = dyv.p; const long lddy = dyv.ld;
@@ -668,7 +669,7 @@ static int train_backward_impl(const ParamView& v, float* grads, const float* mi
   if ((rc = svs_channel_sum_finalize_multi_run(sums, stream))) return rc;    // the encoder bias gradients of this call
   // `stream` is joined with the side stream only by the call that ends the pass (block 1 included); after an earlier
   // part of a split pass the caller uses svs_unet_train_bwd_sync() on the stream that consumes that part's gradients
-  return (parts & 4) ? join() : SVS_OK;
+  return (parts & 8) ? join() : SVS_OK;
 }
 
 extern "C" int svs_unet_train_bwd_sync(hipStream_t consumer) {
@@ -798,8 +799,9 @@ extern "C" int svs_unet_train_bwd_part(const float* params, float* grads, const 
   Geo g; TrainWs t;
   int rc = make_geo(B, H, W, g);
   if (rc) return rc;
-  SVS_REQUIRE(params && grads && mix && part >= 0 && part <= 4, "svs_unet_train_bwd_part: bad arguments");
+  SVS_REQUIRE(params && grads && mix && part >= 0 && part <= 6, "svs_unet_train_bwd_part: bad arguments");
   if ((rc = check_train_ws("svs_unet_train_bwd_part", g, ws, ws_bytes, t))) return rc;
-  static const int bits[5] = {1, 2 | 4, 2, 4, 7};  // decoder | whole encoder | conv6 block | conv5..conv1 blocks | everything
+  // decoder | whole encoder | conv6 block | conv5..conv1 blocks | everything | conv5 + conv4 blocks | conv3..conv1 blocks
+  static const int bits[7] = {1, 2 | 4 | 8, 2, 4 | 8, 15, 4, 8};
   return train_backward_impl(view_params(params), grads, mix, drop, g, t, stream, bits[part]);
 }

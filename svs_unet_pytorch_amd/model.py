@@ -535,10 +535,10 @@ class UNet(nn.Module):
 
     @_on_model_device
     def fwd_bwd_overlapped(self, mix, voc, loss_scale, grad_sync, mix_phase=None, voc_phase=None, alpha_mr=0.0):
-        """Same result as fwd_bwd, as four library calls so that the gradient exchange overlaps the backward:
+        """Same result as fwd_bwd, as five library calls so that the gradient exchange overlaps the backward:
         forward + loss; backward of the decoder half (its gradients occupy the tail of the flat buffer) followed
-        at once by an asynchronous all-reduce of that tail; the conv6 block and its all-reduce; conv5..conv1 and theirs.
-        Returns (loss, [work handles])."""
+        at once by an asynchronous all-reduce of that tail; the conv6 block and its all-reduce; conv5 + conv4 and
+        theirs; conv3..conv1 and theirs.  Returns (loss, [work handles])."""
         mix, voc = self._check_input(mix), self._check_input(voc)
         B, _, H, W = mix.shape
         ws = self._workspace("train", B, H, W)
@@ -551,13 +551,15 @@ class UNet(nn.Module):
         loss = self._fwd_losses(mix, voc, loss_scale, mix_phase, voc_phase, alpha_mr, ws)
         split = int(L.svs_unet_param_offset(24))           # first decoder tensor (deconv1.weight)
         c6 = int(L.svs_unet_param_offset(20))              # conv6.weight: the conv6 block is 13 of the encoder's 17.5 MB
+        c4 = int(L.svs_unet_param_offset(12))              # conv4.weight: conv5 + conv4 are 4.1 MB, conv3..conv1 0.26 MB
         handles = []
-        # decoder -> conv6 block -> conv5..conv1: only the last, 4.4 MB piece is exchanged after the backward has ended
+        # decoder -> conv6 block -> conv5 + conv4 -> conv3..conv1: only the last, 0.26 MB piece is exchanged after the backward
+        # has ended (the backward of the three shallow encoder blocks, ~0.5 ms, hides the 4.1 MB before it)
         main = torch.cuda.current_stream(mix.device)
         if self._xstream is None:
             self._xstream = torch.cuda.Stream(device=mix.device)
         xs = self._xstream
-        for part, sl in ((0, self._gflat[split:]), (2, self._gflat[c6:split]), (3, self._gflat[:c6])):
+        for part, sl in ((0, self._gflat[split:]), (2, self._gflat[c6:split]), (5, self._gflat[c4:c6]), (6, self._gflat[:c4])):
             check(L.svs_unet_train_bwd_part(ptr(self._flat), ptr(self._gflat), ptr(mix), ptr(self._drop), B, H, W, part, ptr(ws),
                                             ws.numel(), _lib.stream_ptr()), "svs_unet_train_bwd_part")
             # the exchange is issued from a stream that waits for this part on BOTH compute streams (the backward's own and

@@ -333,9 +333,10 @@ def test_train_step_learns_and_checkpoint_roundtrip(tmp_path, report):
 
 
 def test_split_backward_equals_fused(report):
-    """The overlapped data-parallel path (forward+loss, then the backward of the decoder blocks, of the conv6 block and
-    of conv5..conv1 as separate library calls with the exchange hook after each) must produce the fused call's
-    gradients bit for bit; the two-piece form of the ABI (part 1 = whole encoder) is checked as well."""
+    """The overlapped data-parallel path (forward+loss, then the backward of the decoder blocks, of the conv6 block, of
+    conv5 + conv4 and of conv3..conv1 as separate library calls with the exchange hook after each) must produce the fused
+    call's gradients bit for bit; the two- and three-piece forms of the ABI (part 1 = whole encoder; parts 0, 2, 3) are
+    checked as well."""
     B = 3
     mix_np, voc_np = synth.tiles(B, first_tile=700)
     mix, voc = torch.from_numpy(mix_np).to(DEV), torch.from_numpy(voc_np).to(DEV)
@@ -361,21 +362,24 @@ def test_split_backward_equals_fused(report):
     la = a.fwd_bwd(mix, voc, loss_scale=166.66)
     sync = FakeSync()
     lb, handles = b.fwd_bwd_overlapped(mix, voc, 166.66, sync)
-    assert la.item() == lb.item() and len(handles) == 3
+    assert la.item() == lb.item() and len(handles) == 4
     assert torch.equal(a._gflat, b._gflat)
-    split, c6 = int(_lib.lib().svs_unet_param_offset(24)), int(_lib.lib().svs_unet_param_offset(20))
+    split, c6, c4 = (int(_lib.lib().svs_unet_param_offset(i)) for i in (24, 20, 12))
     assert sync.calls == [(b._gflat.data_ptr() + 4 * split, b._n_params - split),       # decoder blocks
                           (b._gflat.data_ptr() + 4 * c6, split - c6),                     # conv6 block
-                          (b._gflat.data_ptr(), c6)]                                      # conv1..conv5 blocks
+                          (b._gflat.data_ptr() + 4 * c4, c6 - c4),                        # conv5 + conv4 blocks
+                          (b._gflat.data_ptr(), c4)]                                      # conv1..conv3 blocks
     assert torch.equal(a._bn_flat, b._bn_flat)
     # two-piece form through the ABI on b's state: decoder, then the whole encoder
     L, S = _lib.lib(), _lib.stream_ptr
     ws = b._workspace("train", B, 512, 128)
     g2 = torch.zeros_like(b._gflat)
-    for part in (0, 1):
-        _lib.check(L.svs_unet_train_bwd_part(b._flat.data_ptr(), g2.data_ptr(), mix.data_ptr(), b._drop.data_ptr(), B, 512, 128, part,
-                                             ws.data_ptr(), ws.numel(), S()), "svs_unet_train_bwd_part")
-    assert torch.equal(g2, a._gflat)
+    for parts in ((0, 1), (0, 2, 3), (4,)):
+        g2.zero_()
+        for part in parts:
+            _lib.check(L.svs_unet_train_bwd_part(b._flat.data_ptr(), g2.data_ptr(), mix.data_ptr(), b._drop.data_ptr(), B, 512, 128, part,
+                                                 ws.data_ptr(), ws.numel(), S()), "svs_unet_train_bwd_part")
+        assert torch.equal(g2, a._gflat), parts
     # and a whole step through train_step with the hook
     l2 = b.train_step(mix, voc, loss_scale=166.66, grad_sync=sync)
     l1 = a.train_step(mix, voc, loss_scale=166.66)
