@@ -219,3 +219,32 @@ def test_train_step_b64_oracle_fp32_within_reference_noise(golden):
     for i, n in enumerate(names):
         noise = max(abs(gn32[i] - gn64[i]), 1e-4 * gn64[i], 2e-6)
         assert abs(grads[n].double().norm().item() - gn64[i]) <= 20 * noise, n
+
+
+def test_mrstft_oracle_against_direct_numpy_frames():
+    """oracle/mrstft_oracle.py goes through torch.stft; this restates the same published definition with explicit frames in
+    numpy (reflect padding by n_fft/2, periodic Hann window of win_length centred in the n_fft frame, rfft, clamp, the two
+    terms) so that a slip in the torch.stft arguments cannot hide.  auraloss itself: parity unpinned."""
+    import numpy as np
+    from oracle import mrstft_oracle as mo
+    rng = np.random.default_rng(3)
+    B, L = 2, 6000
+    x = (rng.random((B, L)) - 0.5) * 0.6
+    y = 0.7 * x + (rng.random((B, L)) - 0.5) * 0.2
+    total = 0.0
+    for n_fft, hop, win in zip(mo.FFT_SIZES, mo.HOP_SIZES, mo.WIN_LENGTHS):
+        w = np.zeros(n_fft)
+        w[(n_fft - win) // 2:(n_fft - win) // 2 + win] = 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(win) / win)
+        mags = []
+        for sig in (x, y):
+            pad = np.pad(sig, ((0, 0), (n_fft // 2, n_fft // 2)), mode="reflect")
+            frames = 1 + L // hop
+            fr = np.stack([pad[:, t * hop:t * hop + n_fft] * w for t in range(frames)], axis=1)       # (B, frames, n_fft)
+            spec = np.fft.rfft(fr, axis=-1)
+            mags.append(np.sqrt(np.maximum(spec.real ** 2 + spec.imag ** 2, mo.EPS)))
+        xm, ym = mags
+        sc = np.sqrt(((ym - xm) ** 2).sum()) / np.sqrt((ym ** 2).sum())
+        total += sc + np.abs(np.log(xm) - np.log(ym)).mean()
+    want = total / 3
+    got = float(mo.mrstft_loss(torch.from_numpy(x), torch.from_numpy(y)))
+    assert abs(got - want) <= 1e-10 * abs(want), (got, want)
