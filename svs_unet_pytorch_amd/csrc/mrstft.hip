@@ -222,32 +222,33 @@ struct MrOlaArgs {
 };
 // contributions of padded position q (= p + N/2) of one resolution to its sample: every frame t whose window support
 // covers it, hop t + off <= q < hop t + off + win (off = (N - win) / 2), in ascending t -- a fixed order
-__device__ __forceinline__ float mr_gather(const float* fr, int N, int win, int hop, int F, long q) {
-  const long qq = q - (N - win) / 2;
-  if (qq < 0) return 0.f;
-  long t1 = qq / hop;
+__device__ __forceinline__ float mr_gather(const float* fr, int N, int win, int hop, int F, int q) {
+  const int qq = q - (N - win) / 2;                       // (32-bit throughout: L + n_fft < 2^31 is checked on the host; a 64-bit
+  if (qq < 0) return 0.f;                                 //  division costs ~100 instructions and there were 18 per sample)
+  int t1 = (int)((unsigned)qq / (unsigned)hop);
   if (t1 > F - 1) t1 = F - 1;
-  long t0 = qq - (win - 1);
-  t0 = t0 <= 0 ? 0 : (t0 + hop - 1) / hop;
+  int t0 = qq - (win - 1);
+  t0 = t0 <= 0 ? 0 : (int)((unsigned)(t0 + hop - 1) / (unsigned)hop);
   float s = 0.f;
-  for (long t = t0; t <= t1; ++t) s += fr[t * win + (qq - t * hop)];
+  for (int t = t0; t <= t1; ++t) s += fr[(long)t * win + (qq - t * hop)];
   return s;
 }
 __global__ __launch_bounds__(256) void mr_ola_kernel(MrOlaArgs a) {
-  const long total = (long)a.B * a.L;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const long b = i / a.L, nidx = i - b * a.L;
+  const int L = (int)a.L;
+  // one waveform per blockIdx.y: no division by L per sample
+  const int b = blockIdx.y;
+  for (int nidx = blockIdx.x * 256 + threadIdx.x; nidx < L; nidx += gridDim.x * 256) {
     float s = 0.f;
 #pragma unroll
     for (int r = 0; r < MR_NRES; ++r) {
       const int N = a.n[r], half = N / 2;
-      const float* fr = a.frames[r] + b * (long)a.F[r] * a.win[r];
+      const float* fr = a.frames[r] + (long)b * a.F[r] * a.win[r];
       s += mr_gather(fr, N, a.win[r], a.hop[r], a.F[r], nidx + half);                                 // the sample itself
       if (nidx >= 1 && nidx <= half) s += mr_gather(fr, N, a.win[r], a.hop[r], a.F[r], half - nidx);  // left mirror: p = -n
-      const long pr = 2 * (a.L - 1) - nidx;                                                            // right mirror: p = 2(L-1) - n
-      if (nidx <= a.L - 2 && pr < a.L + half) s += mr_gather(fr, N, a.win[r], a.hop[r], a.F[r], pr + half);
+      const int pr = 2 * (L - 1) - nidx;                                                               // right mirror: p = 2(L-1) - n
+      if (nidx <= L - 2 && pr < L + half) s += mr_gather(fr, N, a.win[r], a.hop[r], a.F[r], pr + half);
     }
-    a.d_x[i] = s;
+    a.d_x[(long)b * L + nidx] = s;
   }
 }
 
@@ -290,7 +291,7 @@ static int mr_launch(bool grad, const MrArgs& a, int B, hipStream_t stream) {
 // loss[0] = MultiResolutionSTFTLoss(x, y); d_x (may be NULL) = grad_scale * d loss / d x.   x, y, d_x: (B, L) fp32.
 extern "C" int svs_mrstft_loss_fwd_bwd(const float* x, const float* y, int B, int64_t L, float grad_scale, float* loss, float* d_x,
                                        void* ws, size_t ws_bytes, hipStream_t stream) {
-  SVS_REQUIRE(x && y && loss && B > 0 && L > 2048, "svs_mrstft_loss_fwd_bwd: bad arguments (need L > 2048 for reflect padding)");
+  SVS_REQUIRE(x && y && loss && B > 0 && B <= 65535 && L > 2048 && L < (1L << 30), "svs_mrstft_loss_fwd_bwd: bad arguments (need 2048 < L < 2^30 -- reflect padding, 32-bit sample indices -- and B <= 65535)");
   const MrWs w = mr_layout(B, L, ws);
   if (!ws || ws_bytes < w.total || !svs_aligned16(ws)) { svs_set_error("svs_mrstft_loss_fwd_bwd: workspace too small (%zu < %zu)", ws_bytes, w.total); return SVS_ERR_WORKSPACE; }
   static_assert(MrCfg<1024>::WIN == 600 && MrCfg<2048>::WIN == 1200 && MrCfg<512>::WIN == 240, "MrCfg::WIN must match MR_WIN");
@@ -317,9 +318,9 @@ extern "C" int svs_mrstft_loss_fwd_bwd(const float* x, const float* y, int B, in
     o.frames[r] = w.frames[r]; o.n[r] = MR_NFFT[r]; o.hop[r] = MR_HOP[r]; o.F[r] = a[r].F; o.win[r] = MR_WIN[r];
   }
   o.B = B; o.L = L; o.d_x = d_x;
-  long g = ((long)B * L + 255) / 256;
-  if (g > 8192) g = 8192;
-  hipLaunchKernelGGL(mr_ola_kernel, dim3((unsigned)g), dim3(256), 0, stream, o);
+  long g = (L + 255) / 256;
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(mr_ola_kernel, dim3((unsigned)g, (unsigned)B), dim3(256), 0, stream, o);
   SVS_CHECK_LAUNCH("mr_ola");
   return SVS_OK;
 }
