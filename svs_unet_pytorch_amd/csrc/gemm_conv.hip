@@ -698,7 +698,8 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
     const long pix = e / N;
     const int n = (int)(e - pix * N);
     f32x4 s = *(const f32x4*)(slab + e);
-    for (int z = 1; z < ksplit; ++z) s += *(const f32x4*)(slab + z * stride + e);
+#pragma unroll 4
+    for (int z = 1; z < ksplit; ++z) s += *(const f32x4*)(slab + z * stride + e);     // (unrolled: four slabs' loads in flight, same order)
     float* dst = y + pix * ldy + n;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {

@@ -401,12 +401,19 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   const int cs = blockIdx.x, cl0 = blockIdx.y * clt;
   const long zstride = (long)Cs * Cl * 25;
   const float* src0 = slab + (long)cs * 25 * Cl + cl0;
-  for (int e = threadIdx.x; e < 25 * clt; e += 256) {
-    const int tap = e / clt, cl = e - tap * clt;
+  // four channels per thread (clt % 4 == 0: Cl % 4 == 0) and four slabs' loads in flight; ascending z as before
+  const int q4 = clt >> 2;
+  for (int e = threadIdx.x; e < 25 * q4; e += 256) {
+    const int tap = e / q4, cl = (e - tap * q4) * 4;
     const float* src = src0 + (long)tap * Cl + cl;
-    float acc = 0.f;
-    for (int z = 0; z < ksplit; ++z) acc += src[z * zstride];
-    tile[tap][cl] = acc;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int z = 0;
+    for (; z + 4 <= ksplit; z += 4, src += 4 * zstride) {
+      const f32x4 a = *(const f32x4*)src, b = *(const f32x4*)(src + zstride), c = *(const f32x4*)(src + 2 * zstride), d = *(const f32x4*)(src + 3 * zstride);
+      acc += a; acc += b; acc += c; acc += d;
+    }
+    for (; z < ksplit; ++z, src += zstride) acc += *(const f32x4*)src;
+    tile[tap][cl] = acc[0]; tile[tap][cl + 1] = acc[1]; tile[tap][cl + 2] = acc[2]; tile[tap][cl + 3] = acc[3];
   }
   __syncthreads();
   float* dst = dw + ((long)cs * Cl + cl0) * 25;
