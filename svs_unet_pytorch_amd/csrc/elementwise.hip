@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void channel_reduce_kernel(BnCtx p, float* __r
         s1 += x * x;
       } else {
         f32x4 dz = *(const f32x4*)(p.dy + pix * p.lddy + cg * 4);
-        if (p.drop) dz *= *(const f32x4*)(p.drop + (pix / p.pps) * p.C + cg * 4);
+        if (p.drop) dz *= *(const f32x4*)(p.drop + (long)((unsigned)pix / (unsigned)p.pps) * p.C + cg * 4);     // (P < 2^31: 32-bit division)
         const f32x4 xm = x - mean4;
         const f32x4 z = xm * k4 + beta4;
 #pragma unroll
@@ -118,18 +118,23 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   }
 }
 
-__global__ __launch_bounds__(256) void bn_act_apply_kernel(BnCtx p, float* __restrict__ y, long ldy) {
-  const int G = p.C >> 2;
-  const long total = p.P * G;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int cg = (int)(i % G);
-    const long pix = i / G;
+// (index arithmetic in 32 bits -- P * C / 4 < 2^32 is checked on the host -- and by shift when C / 4 is a power of two, which it is
+// for every layer of this network: the 64-bit `%` and `/` per float4 made this stream VALU-bound at 4.2 TB/s)
+__global__ __launch_bounds__(256) void bn_act_apply_kernel(BnCtx p, float* __restrict__ y, long ldy, int g_shift) {
+  const unsigned G = (unsigned)p.C >> 2;
+  const unsigned total = (unsigned)(p.P * G);
+  const unsigned pps = (unsigned)p.pps;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    unsigned cg, pixu;
+    if (g_shift >= 0) { cg = i & (G - 1); pixu = i >> g_shift; }
+    else { pixu = i / G; cg = i - pixu * G; }
+    const long pix = pixu;
     const f32x4 x = *(const f32x4*)(p.raw + pix * p.ldr + cg * 4);
     const f32x4 k4 = *(const f32x4*)(p.gamma + cg * 4) * *(const f32x4*)(p.invstd + cg * 4);
     f32x4 z = (x - *(const f32x4*)(p.mean + cg * 4)) * k4 + *(const f32x4*)(p.beta + cg * 4);
 #pragma unroll
     for (int k = 0; k < 4; ++k) z[k] = z[k] > 0.f ? z[k] : z[k] * p.slope;
-    if (p.drop) z *= *(const f32x4*)(p.drop + (pix / p.pps) * p.C + cg * 4);
+    if (p.drop) z *= *(const f32x4*)(p.drop + (long)(pixu / pps) * p.C + cg * 4);
     *(f32x4*)(y + pix * ldy + cg * 4) = z;
   }
 }
@@ -173,7 +178,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnCtx p, const float*
   for (long pix = p0 + pl; pix < p1; pix += PL) {
     const f32x4 x = *(const f32x4*)(p.raw + pix * p.ldr + cg * 4);
     f32x4 dz = *(const f32x4*)(p.dy + pix * p.lddy + cg * 4);
-    if (p.drop) dz *= *(const f32x4*)(p.drop + (pix / p.pps) * p.C + cg * 4);
+    if (p.drop) dz *= *(const f32x4*)(p.drop + (long)((unsigned)pix / (unsigned)p.pps) * p.C + cg * 4);
     const f32x4 xm = x - mean4;
     const f32x4 z = xm * k4 + beta4;
 #pragma unroll
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnCtx p, const float*
 static int check_bn(const char* who, const float* raw, long ldr, long P, int C) {
   SVS_REQUIRE(raw, "%s: null pointer", who);
   SVS_REQUIRE(C >= 4 && C % 4 == 0 && C <= 1024 && (256 % (C / 4) == 0 || (C / 4) % 256 == 0), "%s: unsupported C=%d", who, C);
-  SVS_REQUIRE(P > 0 && ldr >= C && ldr % 4 == 0 && svs_aligned16(raw), "%s: bad view", who);
+  SVS_REQUIRE(P > 0 && P < (1L << 31) && ldr >= C && ldr % 4 == 0 && svs_aligned16(raw), "%s: bad view", who);
   return SVS_OK;
 }
 
@@ -248,7 +253,12 @@ extern "C" int svs_bn_act_apply(const float* raw, int64_t ldr, int64_t P, int C,
   SVS_REQUIRE(y && ldy >= C && ldy % 4 == 0 && svs_aligned16(y), "svs_bn_act_apply: bad output view");
   BnCtx p{}; p.raw = raw; p.ldr = ldr; p.P = P; p.C = C; p.pps = pixels_per_sample;
   p.gamma = gamma; p.beta = beta; p.mean = save_mean; p.invstd = save_invstd; p.slope = slope; p.drop = drop;
-  hipLaunchKernelGGL(bn_act_apply_kernel, dim3(grid_for(P * (C / 4))), dim3(256), 0, stream, p, y, (long)ldy);
+  SVS_REQUIRE(P * (C / 4) < (1L << 32) - 4096L * 256 && pixels_per_sample > 0 && pixels_per_sample < (1L << 31),
+              "svs_bn_act_apply: %ld pixels x %d channels need 64-bit indices; split the batch", (long)P, C);
+  const int G = C / 4;
+  int g_shift = -1;
+  if ((G & (G - 1)) == 0) { g_shift = 0; while ((1 << g_shift) < G) ++g_shift; }
+  hipLaunchKernelGGL(bn_act_apply_kernel, dim3(grid_for(P * (C / 4))), dim3(256), 0, stream, p, y, (long)ldy, g_shift);
   SVS_CHECK_LAUNCH("bn_act_apply");
   return SVS_OK;
 }
@@ -357,8 +367,7 @@ __global__ __launch_bounds__(256) void l1_mask_loss_kernel(const float* __restri
                                                            float* __restrict__ d_logit, float* __restrict__ partial) {
   __shared__ float sh[4];
   float s = 0.f;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    const float m = mask[i], x = mix[i], v = voc[i];
+  auto one = [&](float m, float x, float v, float& dl) __attribute__((always_inline)) {
     const float d1 = m * x - v;
     const float ta = fmaxf(x - v, 0.f);
     const float d2 = (1.f - m) * x - ta;
@@ -366,7 +375,18 @@ __global__ __launch_bounds__(256) void l1_mask_loss_kernel(const float* __restri
     const float s1 = d1 > 0.f ? 1.f : (d1 < 0.f ? -1.f : 0.f);
     const float s2 = d2 > 0.f ? 1.f : (d2 < 0.f ? -1.f : 0.f);
     const float dm = (s1 - s2) * x * gscale;
-    d_logit[i] = dm * m * (1.f - m);
+    dl = dm * m * (1.f - m);
+  };
+  const long n4 = n >> 2;                              // float4 body (all three inputs and d_logit are 16-byte aligned), scalar tail
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const f32x4 m = ((const f32x4*)mask)[i], x = ((const f32x4*)mix)[i], v = ((const f32x4*)voc)[i];
+    f32x4 d;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { float dl; one(m[k], x[k], v[k], dl); d[k] = dl; }
+    ((f32x4*)d_logit)[i] = d;
+  }
+  for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float dl; one(mask[i], mix[i], voc[i], dl); d_logit[i] = dl;
   }
   s = block_sum(s, sh);
   if (threadIdx.x == 0) partial[blockIdx.x] = s;
@@ -390,6 +410,7 @@ extern "C" size_t svs_l1_mask_loss_workspace_bytes(int64_t n) { (void)n; return 
 extern "C" int svs_l1_mask_loss_fwd_bwd(const float* mask, const float* mix, const float* voc, int64_t n, float loss_scale,
                                         float* d_logit, float* loss, void* ws, size_t ws_bytes, hipStream_t stream) {
   SVS_REQUIRE(mask && mix && voc && d_logit && loss && n > 0, "svs_l1_mask_loss_fwd_bwd: null pointer");
+  SVS_REQUIRE(svs_aligned16(mask) && svs_aligned16(mix) && svs_aligned16(voc) && svs_aligned16(d_logit), "svs_l1_mask_loss_fwd_bwd: pointers must be 16-byte aligned");
   if (!ws || ws_bytes < SCALAR_BLOCKS * sizeof(float)) { svs_set_error("svs_l1_mask_loss_fwd_bwd: workspace too small"); return SVS_ERR_WORKSPACE; }
   int nb = (int)((n + 255) / 256);
   if (nb > SCALAR_BLOCKS) nb = SCALAR_BLOCKS;

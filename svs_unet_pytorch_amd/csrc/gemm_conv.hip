@@ -688,14 +688,15 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
                                                               const float* __restrict__ bias,
                                                               const float* __restrict__ scale,
                                                               const float* __restrict__ shift, float slope,
-                                                              float* y, long ldy, int accumulate, float* __restrict__ stats) {
+                                                              float* y, long ldy, int accumulate, float* __restrict__ stats,
+                                                              int n_shift) {      // log2(N) when N is a power of two (every layer here), else -1
   __shared__ f32x4 red[2][256];
   const long total4 = P * N / 4;
   const long stride = P * N;
   f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
     const long e = i * 4;
-    const long pix = e / N;
+    const long pix = n_shift >= 0 ? (e >> n_shift) : e / N;         // (a 64-bit division per float4 otherwise)
     const int n = (int)(e - pix * N);
     f32x4 s = *(const f32x4*)(slab + e);
 #pragma unroll 4
@@ -965,8 +966,10 @@ int svs_conv_gemm_run(int mode, const float* x, long ldx, int B, int H, int W, i
     const bool fuse = stats && stats_nblk && stats_cap >= 2 * N && N % 4 == 0 && N <= 1024 && 256 % (N / 4) == 0 && !scale && !accumulate;
     if (fuse && grid > 512) grid = 512;
     if (fuse && (long)grid * 2 * N > stats_cap) grid = stats_cap / (2 * N);
+    int n_shift = -1;
+    if ((N & (N - 1)) == 0) { n_shift = 0; while ((1 << n_shift) < N) ++n_shift; }
     hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(grid), dim3(256), 0, stream, a.slab, pl.ksplit, P, N, bias, scale,
-                       shift, slope, y, ldy, accumulate, fuse ? stats : nullptr);
+                       shift, slope, y, ldy, accumulate, fuse ? stats : nullptr, n_shift);
     SVS_CHECK_LAUNCH("splitk_epilogue");
     if (fuse) *stats_nblk = grid;
   }
