@@ -399,8 +399,10 @@ __global__ __launch_bounds__(256) void parity_window_bf16_kernel(ConvBf16Args p)
 __global__ __launch_bounds__(256) void splitk_epilogue_bf16_kernel(const float* __restrict__ slab, int ksplit, long P, int N,
                                                                    const float* __restrict__ shift, float slope, u16* y, long ldy) {
   const long total4 = P * N / 4, stride = P * N;
+  int n_shift = -1;                                             // N is a power of two for every layer: no 64-bit division per float4
+  if ((N & (N - 1)) == 0) n_shift = 31 - __builtin_clz((unsigned)N);
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
-    const long e = i * 4, pix = e / N;
+    const long e = i * 4, pix = n_shift >= 0 ? (e >> n_shift) : e / N;
     const int n = (int)(e - pix * N);
     f32x4 s = *(const f32x4*)(slab + e);
     for (int z = 1; z < ksplit; ++z) s += *(const f32x4*)(slab + z * stride + e);

@@ -39,10 +39,11 @@ __global__ __launch_bounds__(256) void conv_c1_kernel(C1Args p) {
   const long pix0 = (long)blockIdx.x * 256;
   const long pix = pix0 + threadIdx.x;
   if (pix < P) {
-    const int ow = (int)(pix % p.Wo);
-    const long tmp = pix / p.Wo;
-    const int oh = (int)(tmp % p.Ho);
-    const long b = tmp / p.Ho;
+    const unsigned upix = (unsigned)pix, utmp = upix / (unsigned)p.Wo;          // (P < 2^31 checked on the host: 32-bit divisions)
+    const int ow = (int)(upix - utmp * (unsigned)p.Wo);
+    const unsigned ub = utmp / (unsigned)p.Ho;
+    const int oh = (int)(utmp - ub * (unsigned)p.Ho);
+    const long b = ub;
     const float* img = p.x + b * p.H * p.W;
     float xin[25];
 #pragma unroll
@@ -96,6 +97,7 @@ int svs_conv_c1_run(const float* x, int B, int H, int W, const float* w, const f
   SVS_REQUIRE(ldy >= (half ? N / 2 : N) && ldy % 4 == 0 && svs_aligned16(y), "%s: bad output view", who);
   C1Args a{x, B, H, W, w, bias, scale, shift, slope, y, ldy, svs_conv_out(H), svs_conv_out(W), accumulate, half};
   const long total = (long)B * a.Ho * a.Wo;
+  SVS_REQUIRE(total < (1L << 31), "%s: %ld output pixels need 64-bit indices; split the batch", who, total);
   const int grid = (int)((total + 255) / 256);
   if (N == 16) hipLaunchKernelGGL(conv_c1_kernel<16>, dim3(grid), dim3(256), 0, stream, a);
   else hipLaunchKernelGGL(conv_c1_kernel<32>, dim3(grid), dim3(256), 0, stream, a);
