@@ -84,10 +84,11 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_kernel(ConvBf16Args p) {
     const long m = m0 + row;
     const bool ok = (row < BM) && (m < M);
     const long mm = ok ? m : 0;
-    const int wq = (int)(mm % Wa);
-    const long tmp = mm / Wa;
-    const int hq = (int)(tmp % Ha);
-    const long b = tmp / Ha;
+    const unsigned um = (unsigned)mm, utmp = um / (unsigned)Wa;      // (M < 2^31, checked on the host: 32-bit divisions)
+    const int wq = (int)(um - utmp * (unsigned)Wa);
+    const unsigned ub = utmp / (unsigned)Ha;
+    const int hq = (int)(utmp - ub * (unsigned)Ha);
+    const long b = ub;
     const int h0 = (MODE == BF_GATHER) ? 2 * hq : hq, w0 = (MODE == BF_GATHER) ? 2 * wq : wq;
     a_voff[r] = ok ? (unsigned)((((b * p.H + h0) * p.W + w0) * p.ldx + chunk * 8) * 2) : OOB;
     unsigned mask = 0;
@@ -188,10 +189,11 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_kernel(ConvBf16Args p) {
     long opix;
     if (MODE == BF_GATHER) opix = m;
     else {
-      const int wq = (int)(m % Wa);
-      const long tmp = m / Wa;
-      const int hq = (int)(tmp % Ha);
-      const long b = tmp / Ha;
+      const unsigned um = (unsigned)m, utmp = um / (unsigned)Wa;
+      const int wq = (int)(um - utmp * (unsigned)Wa);
+      const unsigned ub = utmp / (unsigned)Ha;
+      const int hq = (int)(utmp - ub * (unsigned)Ha);
+      const long b = ub;
       opix = (b * p.Ho + 2 * hq + ph) * p.Wo + 2 * wq + pw;
     }
 #pragma unroll

@@ -125,10 +125,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs p) {
       wq = (int)(pos / (unsigned)Ha);
       hq = (int)(pos - (unsigned)wq * (unsigned)Ha);
     } else {
-      wq = (int)(mm % Wa);
-      const long tmp = mm / Wa;
-      hq = (int)(tmp % Ha);
-      b = tmp / Ha;
+      const unsigned um = (unsigned)mm, utmp = um / (unsigned)Wa;
+      wq = (int)(um - utmp * (unsigned)Wa);
+      const unsigned ub = utmp / (unsigned)Ha;
+      hq = (int)(utmp - ub * (unsigned)Ha);
+      b = ub;
     }
     const int h0 = (MODE == MODE_GATHER) ? 2 * hq : hq;      // anchor pixel of the row
     const int w0 = (MODE == MODE_GATHER) ? 2 * wq : wq;
@@ -286,11 +287,12 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs p) {
         opix = (MODE == MODE_GATHER) ? (b * p.Ho + hq) * p.Wo + wq : (b * p.Ho + 2 * hq + ph) * p.Wo + 2 * wq + pw;
       } else if (MODE == MODE_GATHER) {
         opix = m;
-      } else {
-        const int wq = (int)(m % Wa);
-        const long tmp = m / Wa;
-        const int hq = (int)(tmp % Ha);
-        const long b = tmp / Ha;
+      } else {                                     // (32-bit: M < 2^31, see the prologue; 64-bit divisions cost ~100 instructions each)
+        const unsigned um = (unsigned)m, utmp = um / (unsigned)Wa;
+        const int wq = (int)(um - utmp * (unsigned)Wa);
+        const unsigned ub = utmp / (unsigned)Ha;
+        const int hq = (int)(utmp - ub * (unsigned)Ha);
+        const long b = ub;
         opix = (b * p.Ho + 2 * hq + ph) * p.Wo + 2 * wq + pw;
       }
 #pragma unroll
@@ -377,10 +379,11 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvGemmArgs p) {
     const long m = m0 + i * 16 + lrow;
     const bool ok = m < M;
     const long mm = ok ? m : 0;
-    const int wq = (int)(mm % Wa);
-    const long tmp = mm / Wa;
-    const int hq = (int)(tmp % Ha);
-    const long b = tmp / Ha;
+    const unsigned um = (unsigned)mm, utmp = um / (unsigned)Wa;      // (M < 2^31: 32-bit divisions)
+    const int wq = (int)(um - utmp * (unsigned)Wa);
+    const unsigned ub = utmp / (unsigned)Ha;
+    const int hq = (int)(utmp - ub * (unsigned)Ha);
+    const long b = ub;
     const int h0 = (MODE == MODE_GATHER) ? 2 * hq : hq;
     const int w0 = (MODE == MODE_GATHER) ? 2 * wq : wq;
     a_voff[i] = ok ? (unsigned)((((b * p.H + h0) * p.W + w0) * p.ldx + q * 4) * 4) : OOB;
@@ -450,11 +453,12 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvGemmArgs p) {
       long opix;
       if (MODE == MODE_GATHER) {
         opix = m;
-      } else {
-        const int wq = (int)(m % Wa);
-        const long tmp = m / Wa;
-        const int hq = (int)(tmp % Ha);
-        const long b = tmp / Ha;
+      } else {                                     // (32-bit: M < 2^31, see the prologue; 64-bit divisions cost ~100 instructions each)
+        const unsigned um = (unsigned)m, utmp = um / (unsigned)Wa;
+        const int wq = (int)(um - utmp * (unsigned)Wa);
+        const unsigned ub = utmp / (unsigned)Ha;
+        const int hq = (int)(utmp - ub * (unsigned)Ha);
+        const long b = ub;
         opix = (b * p.Ho + 2 * hq + ph) * p.Wo + 2 * wq + pw;
       }
 #pragma unroll
