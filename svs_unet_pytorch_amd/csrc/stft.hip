@@ -57,13 +57,14 @@ __device__ __forceinline__ float hann_tw(const float2* tw2, int m) {
 __device__ __forceinline__ float hann_fast(int m) { return 0.5f - 0.5f * __builtin_amdgcn_cosf((float)m * (1.0f / NFFT)); }
 
 // window sum-of-squares at padded position q (= sample index + n_fft/2) for T frames of hop `hop`
-__device__ __forceinline__ float envelope_at(long q, int hop, int T) {
-  long t1 = q / hop;
+__device__ __forceinline__ float envelope_at(int q, int hop, int T) {      // (32-bit: two 64-bit divisions per sample were most of the caller)
+  if (q < 0) return 0.f;
+  int t1 = (int)((unsigned)q / (unsigned)hop);
   if (t1 > T - 1) t1 = T - 1;
-  long t0 = q - (NFFT - 1);
-  t0 = t0 <= 0 ? 0 : (t0 + hop - 1) / hop;
+  int t0 = q - (NFFT - 1);
+  t0 = t0 <= 0 ? 0 : (int)((unsigned)(t0 + hop - 1) / (unsigned)hop);
   float env = 0.f;
-  for (long t = t0; t <= t1; ++t) { const float w = hann_at((int)(q - t * hop)); env += w * w; }
+  for (int t = t0; t <= t1; ++t) { const float w = hann_fast(q - t * hop); env += w * w; }
   return env;
 }
 
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(512) void stft_fwd_kernel(StftArgs p) {
       }
       if (SRC == SRC_ENVDIV) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { const float env = envelope_at(q0 + j, p.hop, p.T); if (env > 1.1754944e-38f) v[r][h][j] /= env; }
+        for (int j = 0; j < 4; ++j) { const float env = envelope_at((int)(q0 + j), p.hop, p.T); if (env > 1.1754944e-38f) v[r][h][j] *= __builtin_amdgcn_rcpf(env); }   // (as the inverse itself divides)
       }
     }
   }
