@@ -174,9 +174,9 @@ __global__ __launch_bounds__(512) void stft_fwd_kernel(StftArgs p) {
       // d|S| = Re(conj(e^{i phi}) G)
       const bool edge = (k == 0 || k == NFFT / 2);
       const float ck = edge ? 1.0f / NFFT : 2.0f / NFFT;
-      float sa, ca, sb, cb;
-      sincosf(angs[k * SROW + 2 * wave], &sa, &ca);
-      sincosf(angs[k * SROW + 2 * wave + 1], &sb, &cb);
+      // (the same one-instruction phasors as the inverse it is the transpose of)
+      const float ra = angs[k * SROW + 2 * wave] * 0.15915494309189535f, rb = angs[k * SROW + 2 * wave + 1] * 0.15915494309189535f;
+      const float sa = __builtin_amdgcn_sinf(ra), ca = __builtin_amdgcn_cosf(ra), sb = __builtin_amdgcn_sinf(rb), cb = __builtin_amdgcn_cosf(rb);
       out = float2{ck * (A[r].x * ca + (edge ? 0.f : A[r].y * sa)), ck * (B[r].x * cb + (edge ? 0.f : B[r].y * sb))};
     }
     fbuf[xpose_at(wave, k)] = out;
