@@ -602,13 +602,16 @@ __global__ __launch_bounds__(256) void pack_all_kernel(SvsPackJobs jobs) {
   const SvsPackJob jb = jobs.j[ji];
   const int n = blockIdx.x - jb.first_block;
   const int C = jb.C, N = jb.N, tot = C * 25;
+  // C is a power of two for every layer (16 .. 512): index splits by shift / mask (the runtime divisions were most of the
+  // kernel's instructions); lc < 0 keeps the general form
+  const int lc = (C & (C - 1)) == 0 ? 31 - __builtin_clz((unsigned)C) : -1;
   if (jb.kind == 0) {           // gather: w[n][c][tap] -> wp[n][tap][c]
     const float* src = jb.w + (long)n * tot;
     for (int e = threadIdx.x; e < tot; e += 256) tile[e] = src[e];
     __syncthreads();
     float* dst = jb.wp + (long)n * tot;
     for (int e = threadIdx.x; e < tot; e += 256) {
-      const int tap = e / C, c = e - tap * C;
+      const int tap = lc >= 0 ? e >> lc : e / C, c = e - tap * C;
       dst[e] = tile[c * 25 + tap];
     }
   } else {                      // parity: w[c][n][tap] -> wp[p][n][th][tw][c]
@@ -624,8 +627,8 @@ __global__ __launch_bounds__(256) void pack_all_kernel(SvsPackJobs jobs) {
       const int poff = (par == 0) ? 0 : (par == 1) ? 9 : (par == 2) ? 15 : 21;
       float* dst = jb.wp + poff * NC + (long)n * ntaps * C;
       for (int e = threadIdx.x; e < ntaps * C; e += 256) {
-        const int t2 = e / C, c = e - t2 * C;
-        const int th = t2 / ntw, tw = t2 - th * ntw;
+        const int t2 = lc >= 0 ? e >> lc : e / C, c = e - t2 * C;
+        const int th = t2 / ntw, tw = t2 - th * ntw;            // (ntw is 3 or 2: compile-time after unrolling)
         dst[e] = tile[c * 25 + (ph + 2 * th) * 5 + pw + 2 * tw];
       }
     }
