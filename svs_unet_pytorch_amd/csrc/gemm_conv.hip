@@ -496,7 +496,8 @@ __device__ __forceinline__ void svs_static_for(F&& f) {        // f(integral_con
 // rows (two 16-pixel row tiles); the weight fragments come straight from global memory (they are shared by
 // every block, so they live in L2/L1) and are prefetched one tap ahead.
 // ------------------------------------------------------------------------------------------------
-template <int C, int CW, int TN>              // C input channels, CW of them per staging phase; N = 16 * TN
+template <int C, int CW, int TN, int NT = TN>  // C input channels, CW of them per staging phase; N = 16 * NT, of which a block
+                                               // computes 16 * TN (blockIdx.y picks them: small batches get NT / TN x the blocks)
 __global__ __launch_bounds__(256) void parity_window_kernel(ConvGemmArgs p) {
   constexpr int TH = 8, TW = 16, TM = 2;
   constexpr int LP = CW + 4;                   // floats per staged pixel: 16-byte aligned, conflict-free b128 reads
@@ -543,8 +544,9 @@ __global__ __launch_bounds__(256) void parity_window_kernel(ConvGemmArgs p) {
   // step s + 1 (possibly the next class's first tap) are requested before step s's MFMAs, and a scheduling barrier
   // after every step keeps the compiler from hoisting later steps' loads on top (which costs a third of the occupancy).
   unsigned b_voff[TN];
+  const int n0 = NT > TN ? (int)blockIdx.y * (TN * 16) : 0;
 #pragma unroll
-  for (int j = 0; j < TN; ++j) b_voff[j] = (unsigned)((j * 16 + lrow) * C * 4);   // one tap's row pitch; x ntaps of the class below
+  for (int j = 0; j < TN; ++j) b_voff[j] = (unsigned)((n0 + j * 16 + lrow) * C * 4);   // one tap's row pitch; x ntaps of the class below
   f32x4 fb[2][CC][TN];
   auto load_b = [&](auto sc, int phase) {
     constexpr int s_ = decltype(sc)::value;
@@ -557,7 +559,7 @@ __global__ __launch_bounds__(256) void parity_window_kernel(ConvGemmArgs p) {
 #pragma unroll
       for (int j = 0; j < TN; ++j)
         fb[s_ & 1][cc][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-            rw, (int)(b_voff[j] * ntaps + q * 16 + phase * (CW * 4)), (POFF[par] * (TN * 16) * C + tap * C + cc * 16) * 4, 0));
+            rw, (int)(b_voff[j] * ntaps + q * 16 + phase * (CW * 4)), (POFF[par] * (NT * 16) * C + tap * C + cc * 16) * 4, 0));
   };
   auto step = [&](auto sc, f32x4 (&acc)[TM][TN]) {
     constexpr int s_ = decltype(sc)::value;
@@ -604,7 +606,7 @@ __global__ __launch_bounds__(256) void parity_window_kernel(ConvGemmArgs p) {
         const long opix = (b * p.Ho + oh) * p.Wo + ow;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          const int n = j * 16 + lrow;
+          const int n = n0 + j * 16 + lrow;
           float v = acc[i][j][r];
           if (p.bias) v += p.bias[n];
           if (p.scale) {
@@ -677,9 +679,9 @@ __global__ __launch_bounds__(256) void parity_window_kernel(ConvGemmArgs p) {
     }
     __syncthreads();
     if (t < TN * 16) {
-      float* out = p.stats + (long)blockIdx.x * 2 * (TN * 16);
+      float* out = p.stats + (long)blockIdx.x * 2 * (NT * 16) + n0;
       out[t] = (st[0][0][t] + st[0][1][t]) + (st[0][2][t] + st[0][3][t]);
-      out[TN * 16 + t] = (st[1][0][t] + st[1][1][t]) + (st[1][2][t] + st[1][3][t]);
+      out[NT * 16 + t] = (st[1][0][t] + st[1][1][t]) + (st[1][2][t] + st[1][3][t]);
     }
   }
 }
@@ -844,9 +846,9 @@ static int use_parity_window(int mode, int B, int H, int W, int C, int N, long l
                         ((long)H * W * ldx) * 4 < (1L << 31);
   const bool fills_gpu = H >= 8 && W >= 16 && (long)B * ((H + 7) / 8) * ((W + 15) / 16) >= 128;   // (B=16 sweep: still ahead of the direct kernel at 128 blocks)
   int window = eligible && fills_gpu;
-  if (svs_tune_on(SVS_TUNE_CONV_WINDOW)) {     // sweeps and tests: 0 = never, 2 = whenever the shape is eligible
-    const int f = (int)svs_tune(SVS_TUNE_CONV_WINDOW);
-    window = (f == 0) ? 0 : (f == 2) ? eligible : window;
+  if (svs_tune_on(SVS_TUNE_CONV_WINDOW)) {     // sweeps and tests: 0 = never, 2 = whenever the shape is eligible, 3 = same and
+    const int f = (int)svs_tune(SVS_TUNE_CONV_WINDOW);          // never with the channel halves in separate blocks
+    window = (f == 0) ? 0 : (f >= 2) ? eligible : window;
   }
   return window;
 }
@@ -932,6 +934,12 @@ int svs_conv_gemm_run(int mode, const float* x, long ldx, int B, int H, int W, i
 #define SVS_LAUNCH_WINDOW(C_, CW_, TN_) hipLaunchKernelGGL((parity_window_kernel<C_, CW_, TN_>), grid, dim3(256), 0, stream, a)
     if (N == 16) {
       if (C == 32) SVS_LAUNCH_WINDOW(32, 32, 1); else if (C == 64) SVS_LAUNCH_WINDOW(64, 64, 1); else SVS_LAUNCH_WINDOW(128, 64, 1);
+    } else if (grid.x < 256 && !(svs_tune_on(SVS_TUNE_CONV_WINDOW) && svs_tune(SVS_TUNE_CONV_WINDOW) == 3)) {
+      // fewer tiles than CUs (batch 16): the two 16-channel halves go to different blocks (each stages the window itself)
+      grid.y = 2;
+#define SVS_LAUNCH_WINDOW_HALF(C_, CW_) hipLaunchKernelGGL((parity_window_kernel<C_, CW_, 1, 2>), grid, dim3(256), 0, stream, a)
+      if (C == 32) SVS_LAUNCH_WINDOW_HALF(32, 32); else if (C == 64) SVS_LAUNCH_WINDOW_HALF(64, 64); else SVS_LAUNCH_WINDOW_HALF(128, 64);
+#undef SVS_LAUNCH_WINDOW_HALF
     } else {
       if (C == 32) SVS_LAUNCH_WINDOW(32, 32, 2); else if (C == 64) SVS_LAUNCH_WINDOW(64, 64, 2); else SVS_LAUNCH_WINDOW(128, 64, 2);
     }

@@ -43,18 +43,21 @@ __global__ __launch_bounds__(256) void conv_c1_kernel(C1Args p) {
     const int ow = (int)(upix - utmp * (unsigned)p.Wo);
     const unsigned ub = utmp / (unsigned)p.Ho;
     const int oh = (int)(utmp - ub * (unsigned)p.Ho);
-    const long b = ub;
-    const float* img = p.x + b * p.H * p.W;
+    // the 25 samples as buffer loads: taps outside the image get an out-of-range offset and read as zero, so there is
+    // no branch around any load (25 exec-masked regions before) and all of them are in flight together
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, OOB, 0x00020000);
+    const int img = (int)ub * p.H * p.W;                                        // (whole input < 2 GiB checked on the host)
     float xin[25];
 #pragma unroll
     for (int kh = 0; kh < 5; ++kh) {
       const int ih = 2 * oh - 2 + kh;
+      const bool okh = (unsigned)ih < (unsigned)p.H;
 #pragma unroll
       for (int kw = 0; kw < 5; ++kw) {
         const int iw = 2 * ow - 2 + kw;
-        float v = 0.f;
-        if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) v = img[(long)ih * p.W + iw];
-        xin[kh * 5 + kw] = v;
+        const unsigned vo = (okh && (unsigned)iw < (unsigned)p.W) ? (unsigned)(img + ih * p.W + iw) * 4u : OOB;
+        xin[kh * 5 + kw] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (int)vo, 0, 0));
       }
     }
 #pragma unroll
@@ -98,6 +101,7 @@ int svs_conv_c1_run(const float* x, int B, int H, int W, const float* w, const f
   C1Args a{x, B, H, W, w, bias, scale, shift, slope, y, ldy, svs_conv_out(H), svs_conv_out(W), accumulate, half};
   const long total = (long)B * a.Ho * a.Wo;
   SVS_REQUIRE(total < (1L << 31), "%s: %ld output pixels need 64-bit indices; split the batch", who, total);
+  SVS_REQUIRE((long)B * H * W * 4 < (1L << 31), "%s: the input must span < 2 GiB (32-bit buffer offsets); split the batch", who);
   const int grid = (int)((total + 255) / 256);
   if (N == 16) hipLaunchKernelGGL(conv_c1_kernel<16>, dim3(grid), dim3(256), 0, stream, a);
   else hipLaunchKernelGGL(conv_c1_kernel<32>, dim3(grid), dim3(256), 0, stream, a);

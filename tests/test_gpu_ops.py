@@ -190,17 +190,28 @@ def test_mfma_split_mode_accuracy(kind, B, H, W, C, N, report, tune):
 
 
 def test_enc_block_fwd_c1(report):
-    for (B, H, W, N) in ((2, 64, 32, 16), (1, 33, 17, 16), (2, 32, 32, 32)):
+    for (B, H, W, N) in ((2, 64, 32, 16), (1, 33, 17, 16), (2, 32, 32, 32), (3, 21, 9, 32), (1, 4, 2, 16)):
         x = rnd((B, 1, H, W), 20, 0, 1)
         w = rnd((N, 1, 5, 5), 21, -0.2, 0.2)
         b = rnd((N,), 22)
         want = F.conv2d(x.double(), w.double(), b.double(), stride=2, padding=2)
         Ho, Wo = (H + 1) // 2, (W + 1) // 2
-        y = torch.empty((B, Ho, Wo, N), device=DEV)
+        y = torch.full((B, Ho, Wo, N + 8), 7.0, device=DEV)       # strided output view: the pad columns stay untouched
         xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
         _lib.check(L().svs_enc_block_fwd(xd.data_ptr(), 1, B, H, W, 1, wd.data_ptr(), bd.data_ptr(), None, None, 0.0,
-                                         y.data_ptr(), N, N, 0, None, 0, S()))
-        assert report(f"enc_fwd_c1 B{B} {H}x{W} N{N}", relerr(nchw(y), want), 1e-5)
+                                         y.data_ptr(), N + 8, N, 0, None, 0, S()))
+        assert torch.all(y[..., N:] == 7.0)
+        assert report(f"enc_fwd_c1 B{B} {H}x{W} N{N}", relerr(nchw(y[..., :N]), want), 1e-5)
+        # folded-BatchNorm epilogue + LeakyReLU, then the same call accumulating onto its own result
+        sc, sh = rnd((N,), 23, 0.5, 1.5), rnd((N,), 24)
+        want2 = F.leaky_relu(F.conv2d(x.double(), w.double(), None, stride=2, padding=2) * sc.double()[None, :, None, None]
+                             + sh.double()[None, :, None, None], 0.2)
+        y2 = torch.empty((B, Ho, Wo, N), device=DEV)
+        scd, shd = sc.to(DEV), sh.to(DEV)
+        for acc in (0, 1):
+            _lib.check(L().svs_enc_block_fwd(xd.data_ptr(), 1, B, H, W, 1, wd.data_ptr(), None, scd.data_ptr(), shd.data_ptr(), 0.2,
+                                             y2.data_ptr(), N, N, acc, None, 0, S()))
+            assert report(f"enc_fwd_c1 epi acc={acc} B{B} {H}x{W} N{N}", relerr(nchw(y2), (1 + acc) * want2), 1e-5)
 
 
 DEC_CASES = [
@@ -259,9 +270,10 @@ WINDOW_CASES = [
 ]
 
 
-@pytest.mark.parametrize("B,H,W,C,N,Ho,Wo", WINDOW_CASES)
-def test_parity_window_kernel(B, H, W, C, N, Ho, Wo, report, tune):
-    tune("CONV_WINDOW", 2)
+# 32 output channels: once with the two 16-channel halves in separate blocks (what grids below 256 tiles get), once whole
+@pytest.mark.parametrize("B,H,W,C,N,Ho,Wo,force", [c + (2,) for c in WINDOW_CASES] + [c + (3,) for c in WINDOW_CASES if c[4] == 32])
+def test_parity_window_kernel(B, H, W, C, N, Ho, Wo, force, report, tune):
+    tune("CONV_WINDOW", force)
     buf = ctypes.create_string_buffer(128)
     L().svs_describe_plan(1, B, H, W, C, Ho, Wo, N, buf, 128)
     assert buf.value.decode().startswith("parity_window_kernel"), buf.value
