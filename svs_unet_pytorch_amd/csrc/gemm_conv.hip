@@ -848,9 +848,15 @@ static int use_parity_window(int mode, int B, int H, int W, int C, int N, long l
   int window = eligible && fills_gpu;
   if (svs_tune_on(SVS_TUNE_CONV_WINDOW)) {     // sweeps and tests: 0 = never, 2 = whenever the shape is eligible, 3 = same and
     const int f = (int)svs_tune(SVS_TUNE_CONV_WINDOW);          // never with the channel halves in separate blocks
-    window = (f == 0) ? 0 : (f >= 2) ? eligible : window;
+    window = (f == 0) ? 0 : (f == 2 || f == 3) ? eligible : window;
   }
   return window;
+}
+
+// 32 output channels and at most one tile per CU (batch <= 32): the two 16-channel halves go to different blocks, each
+// staging the window itself (same-device A/B of the eval forward: batch 16 -7 %, batch 32 -1 %, batch 64 +2 %)
+static bool parity_window_halves(long tiles) {
+  return tiles <= 256 && !(svs_tune_on(SVS_TUNE_CONV_WINDOW) && svs_tune(SVS_TUNE_CONV_WINDOW) == 3);
 }
 
 static bool narrow_level(int mode, int B, int C, int Wo, int N) {
@@ -934,8 +940,7 @@ int svs_conv_gemm_run(int mode, const float* x, long ldx, int B, int H, int W, i
 #define SVS_LAUNCH_WINDOW(C_, CW_, TN_) hipLaunchKernelGGL((parity_window_kernel<C_, CW_, TN_>), grid, dim3(256), 0, stream, a)
     if (N == 16) {
       if (C == 32) SVS_LAUNCH_WINDOW(32, 32, 1); else if (C == 64) SVS_LAUNCH_WINDOW(64, 64, 1); else SVS_LAUNCH_WINDOW(128, 64, 1);
-    } else if (grid.x < 256 && !(svs_tune_on(SVS_TUNE_CONV_WINDOW) && svs_tune(SVS_TUNE_CONV_WINDOW) == 3)) {
-      // fewer tiles than CUs (batch 16): the two 16-channel halves go to different blocks (each stages the window itself)
+    } else if (parity_window_halves(grid.x)) {
       grid.y = 2;
 #define SVS_LAUNCH_WINDOW_HALF(C_, CW_) hipLaunchKernelGGL((parity_window_kernel<C_, CW_, 1, 2>), grid, dim3(256), 0, stream, a)
       if (C == 32) SVS_LAUNCH_WINDOW_HALF(32, 32); else if (C == 64) SVS_LAUNCH_WINDOW_HALF(64, 64); else SVS_LAUNCH_WINDOW_HALF(128, 64);
@@ -1013,11 +1018,15 @@ int svs_conv_gemm_describe(int mode, int B, int H, int W, int C, int Ho, int Wo,
     if (N == 16) direct = 1;
     else if (N == 32 && mode == MODE_PARITY && C >= 128) direct = 1;
   }
-  if (use_parity_window(mode, B, H, W, C, N, ldx)) { snprintf(buf, n, "parity_window_kernel<%d, %d, %d>", C, C == 32 ? 32 : 64, N / 16); return 1; }
+  if (use_parity_window(mode, B, H, W, C, N, ldx)) {
+    const bool halves = N == 32 && parity_window_halves((long)B * ((H + 7) / 8) * ((W + 15) / 16));
+    snprintf(buf, n, "parity_window_kernel<%d, %d, %d, %d>", C, C == 32 ? 32 : 64, halves ? 1 : N / 16, N / 16);
+    return 1;
+  }
   if (direct) { snprintf(buf, n, "conv_direct_kernel<%d, 4, %d>", mode, N / 16); return 1; }
   static const int wm[10] = {2, 2, 4, 4, 1, 2, 2, 4, 4, 4}, wn[10] = {2, 2, 1, 1, 4, 2, 2, 1, 1, 1};     // (6 = 64x128, 2x2 waves)
   const ConvPlan pl = plan_conv(mode, Mmax, N, nkt_min, narrow_level(mode, B, C, Wo, N));
-  snprintf(buf, n, "conv_gemm_kernel<%d, %d, %d, %d, %d, %s>", mode, pl.BM, pl.BN, wm[pl.cfg], wn[pl.cfg],
-           use_tap_skip(mode, B, C, Wo, N, pl.cfg) ? "true" : "false");
+  snprintf(buf, n, "conv_gemm_kernel<%d, %d, %d, %d, %d, %s, %s>", mode, pl.BM, pl.BN, wm[pl.cfg], wn[pl.cfg],
+           use_tap_skip(mode, B, C, Wo, N, pl.cfg) ? "true" : "false", svs_tune(SVS_TUNE_MFMA_SPLIT) > 0 ? "true" : "false");
   return pl.ksplit;
 }

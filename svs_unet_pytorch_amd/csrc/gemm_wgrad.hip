@@ -571,7 +571,7 @@ int svs_wgrad_gemm_describe(int B, int Hs, int Ws, int Cs, int Cl, char* buf, si
   const WgWinPlan wp = plan_wgrad_window(B, Hs, Ws, Cs, Cl);
   if (wp.use) { snprintf(buf, n, "wgrad_window_kernel<%d>", wp.MT); return wp.nslab; }
   const WgradPlan pl = plan_wgrad(B, Hs, Ws, Cs, Cl);
-  snprintf(buf, n, "wgrad_gemm_kernel<%d, %d, %d, %d, %s>", pl.BM, pl.BN, pl.cfg == 0 ? 2 : 1, pl.cfg == 0 ? 2 : 4,
-           use_wgrad_skip(B, Hs, Ws, Cl, Cs, pl.cfg) ? "true" : "false");
+  snprintf(buf, n, "wgrad_gemm_kernel<%d, %d, %d, %d, %s, %s>", pl.BM, pl.BN, pl.cfg == 0 ? 2 : 1, pl.cfg == 0 ? 2 : 4,
+           use_wgrad_skip(B, Hs, Ws, Cl, Cs, pl.cfg) ? "true" : "false", svs_tune(SVS_TUNE_MFMA_SPLIT) > 0 ? "true" : "false");
   return pl.ksplit;
 }
