@@ -425,36 +425,36 @@ def main():
         }
         if strong is not None:
             res["strong_b512"] = strong
+        if not args.no_layers:         # rank 0's GPU, any world size: the dominant kernel's roofline record
+            calls = time_gemm_calls(B, args.mode)
+            fam = {}
+            for name, kernel, ks, ms, gf, _ in calls:
+                e = fam.setdefault(kernel, [0.0, 0.0, 0])
+                e[0] += ms; e[1] += gf; e[2] += 1
+            dom = max(fam, key=lambda k: fam[k][0])
+            # the dominant kernel ALONE (its fixed-order slab reduction is a separate kernel in the rocprofv3
+            # summary): same calls again with the reduction skipped, so that avg_launch_ms is comparable with
+            # the summary's average duration of that kernel
+            _lib.tuning("SKIP_REDUCE", 1)
+            alone = [c for c in time_gemm_calls(B, args.mode, only_kernel=dom)]
+            _lib.tuning("SKIP_REDUCE", -1)
+            ms, gf, cnt = sum(c[3] for c in alone), sum(c[4] for c in alone), len(alone)
+            gf_in_image = sum(c[4] * c[5] for c in alone)
+            ach = gf / ms            # GFLOP / ms = TFLOP/s
+            res["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(dom)[0], "traffic_source": pmc_traffic(dom)[1],
+                               "launches_per_step": cnt, "avg_launch_ms": round(ms / cnt, 4),
+                               "algorithmic_gflop_per_launch": round(gf / cnt, 3),
+                               "achieved_in_image": round(gf_in_image / ms, 2),
+                               "frac_in_image": round(gf_in_image / ms / FP32_MFMA_PEAK_TFLOPS, 4),
+                               "note": "HIP events on the launch stream around each launch of this kernel in one step "
+                                       "(slab reductions excluded); algorithmic FLOPs = 2*M*N*K of the layer (SURVEY.md 8d); "
+                                       "*_in_image counts only products whose tap is inside the image -- the share the "
+                                       "padding-skipping kernels cannot avoid executing is between the two"}
+            res["kernels"] = {k: {"calls": v[2], "ms": round(v[0], 4), "tflops": round(v[1] / v[0], 2)} for k, v in fam.items()}
+            res["layers"] = {name: {"kernel": kernel, "ksplit": ks, "ms": round(ms, 4), "tflops": round(gf / ms, 2),
+                                    "in_image": round(fr, 3)} for name, kernel, ks, ms, gf, fr in calls}
         if world == 1:
-            if not args.no_layers:
-                calls = time_gemm_calls(B, args.mode)
-                fam = {}
-                for name, kernel, ks, ms, gf, _ in calls:
-                    e = fam.setdefault(kernel, [0.0, 0.0, 0])
-                    e[0] += ms; e[1] += gf; e[2] += 1
-                dom = max(fam, key=lambda k: fam[k][0])
-                # the dominant kernel ALONE (its fixed-order slab reduction is a separate kernel in the rocprofv3
-                # summary): same calls again with the reduction skipped, so that avg_launch_ms is comparable with
-                # the summary's average duration of that kernel
-                _lib.tuning("SKIP_REDUCE", 1)
-                alone = [c for c in time_gemm_calls(B, args.mode, only_kernel=dom)]
-                _lib.tuning("SKIP_REDUCE", -1)
-                ms, gf, cnt = sum(c[3] for c in alone), sum(c[4] for c in alone), len(alone)
-                gf_in_image = sum(c[4] * c[5] for c in alone)
-                ach = gf / ms            # GFLOP / ms = TFLOP/s
-                res["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                                   "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(dom)[0], "traffic_source": pmc_traffic(dom)[1],
-                                   "launches_per_step": cnt, "avg_launch_ms": round(ms / cnt, 4),
-                                   "algorithmic_gflop_per_launch": round(gf / cnt, 3),
-                                   "achieved_in_image": round(gf_in_image / ms, 2),
-                                   "frac_in_image": round(gf_in_image / ms / FP32_MFMA_PEAK_TFLOPS, 4),
-                                   "note": "HIP events on the launch stream around each launch of this kernel in one step "
-                                           "(slab reductions excluded); algorithmic FLOPs = 2*M*N*K of the layer (SURVEY.md 8d); "
-                                           "*_in_image counts only products whose tap is inside the image -- the share the "
-                                           "padding-skipping kernels cannot avoid executing is between the two"}
-                res["kernels"] = {k: {"calls": v[2], "ms": round(v[0], 4), "tflops": round(v[1] / v[0], 2)} for k, v in fam.items()}
-                res["layers"] = {name: {"kernel": kernel, "ksplit": ks, "ms": round(ms, 4), "tflops": round(gf / ms, 2),
-                                        "in_image": round(fr, 3)} for name, kernel, ks, ms, gf, fr in calls}
             if not args.no_extras:
                 if args.mode == "train":
                     res["optional_mfma_split"] = split_mode_record(model, dev, B)
