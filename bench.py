@@ -239,6 +239,38 @@ def split_mode_record(model, dev, B=64, steps=20, warmup=5):
         out[name] = {"ms_per_step": round(ms, 4), "tiles_per_s": round(B / ms * 1e3, 1)}
     _lib.tuning("MFMA_SPLIT", -1)
     out["note"] = "same process, same device, back to back; `value` above is the default mode"
+    try:
+        out["accuracy_vs_float64"] = split_mode_accuracy(dev)
+    except Exception as e:                       # a diagnostic, never a reason to lose the bench line
+        out["accuracy_error"] = str(e)[:200]
+    return out
+
+
+def split_mode_accuracy(dev, B=4, H=32, W=16, C=128, N=256):
+    """Both product modes of the conv GEMM on the same operands (four decades of dynamic range) against torch's float64
+    convolution on the CPU: error relative to sum |x w| per output, the scale of a dot product's rounding error
+    (tests/test_gpu_ops.py::test_mfma_split_mode_accuracy is the gated version of this, on four kinds of call)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(7)
+    spread = lambda shape: (torch.rand(shape, generator=g) - 0.5) * torch.exp(4.0 * (torch.rand(shape, generator=g) - 0.5))
+    x, w = spread((B, C, H, W)), spread((N, C, 5, 5)) * 0.1
+    want = F.conv2d(x.double(), w.double(), None, stride=2, padding=2)
+    mag = F.conv2d(x.double().abs(), w.double().abs(), None, stride=2, padding=2)
+    L, S = _lib.lib(), _lib.stream_ptr
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    wd, wp = w.to(dev).contiguous(), torch.empty(N * C * 25, device=dev)
+    _lib.check(L.svs_pack_weight_gather(wd.data_ptr(), wp.data_ptr(), N, C, S()), "svs_pack_weight_gather")
+    ws = torch.empty(max(int(L.svs_enc_block_workspace_bytes(B, H, W, C, N)), 16), dtype=torch.uint8, device=dev)
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    out = {"call": f"svs_enc_block_fwd B{B} {H}x{W} C{C} N{N}, error / sum|x w|"}
+    for name, val in (("fp32_mfma", -1), ("mfma_split", 1)):
+        _lib.tuning("MFMA_SPLIT", val)
+        y = torch.empty((B, Ho, Wo, N), device=dev)
+        _lib.check(L.svs_enc_block_fwd(xd.data_ptr(), C, B, H, W, C, wp.data_ptr(), None, None, None, 0.0, y.data_ptr(), N, N, 0,
+                                       ws.data_ptr(), ws.numel(), S()), "svs_enc_block_fwd")
+        err = (y.permute(0, 3, 1, 2).cpu().double() - want).abs() / mag
+        out[name] = {"max": float(f"{err.max().item():.3e}"), "mean": float(f"{err.mean().item():.3e}")}
+    _lib.tuning("MFMA_SPLIT", -1)
     return out
 
 
