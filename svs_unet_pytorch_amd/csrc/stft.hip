@@ -349,7 +349,6 @@ __global__ __launch_bounds__(512, 2) void istft_kernel(IstftArgs p, int ngroups)
   fft_wave<NFFT>(buf, tw, lane);
   __syncthreads();
   // ---- output: sample rel = hop * (f - 1) + m of local frame f; at most frames f_hi (m < hop) and f_hi - 1 (m + hop < n_fft)
-  const int span = IGROUP * p.hop;
   float vmax = 0.f;
   {
     // A thread keeps its position m inside the hop and walks the 15 hops: the two window values (and, away from the ends of
