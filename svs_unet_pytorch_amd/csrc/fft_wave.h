@@ -87,11 +87,16 @@ template <int N, int R, int NS>
 struct FftPass {
   static constexpr int NB = N / R / 64;                  // butterflies per lane
   float2 v[NB][R];
+  // Padded indices as (one lane-dependent base) + (compile-time constant), so that every access of a pass is one base register
+  // and an immediate offset: pad(a + c) = pad(a) + pad(c) whenever c is a multiple of 16 (the shift cannot carry), which the
+  // compiler does not derive by itself from i + (i >> 4) -- it built a separate address for most of the 16 accesses.
+  static_assert((N / R) % 64 == 0, "pass stride");
   FFT_HD void load(const float2* buf, int lane) {
+    const float2* base = buf + fft_pad(lane);
 #pragma unroll
     for (int b = 0; b < NB; ++b)
 #pragma unroll
-      for (int t = 0; t < R; ++t) v[b][t] = buf[fft_pad(lane + 64 * b + t * (N / R))];
+      for (int t = 0; t < R; ++t) v[b][t] = base[fft_pad(64 * b + t * (N / R))];
   }
   FFT_HD void compute(const float2* tw, int lane) {      // tw: this pass's table ([t][k]); unused when NS == 1
 #pragma unroll
@@ -105,12 +110,37 @@ struct FftPass {
     }
   }
   FFT_HD void store(float2* buf, int lane) {
+    if constexpr (NS == 1 && (R == 16 || R == 8)) {
+      // element (lane + 64 b) R + t: the low four bits of lane R are 0 (R = 16) or 0 / 8 (R = 8), so adding t < R never carries
+      // into the padding shift: pad = pad(lane R) + t + pad(64 b R)
+      float2* base = buf + fft_pad(lane * R);
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      const int j = lane + 64 * b, k = j & (NS - 1);
-      const int j0 = (j - k) * R + k;
+      for (int b = 0; b < NB; ++b)
 #pragma unroll
-      for (int t = 0; t < R; ++t) buf[fft_pad(j0 + t * NS)] = v[b][fft_bitrev<R>(t)];
+        for (int t = 0; t < R; ++t) base[t + fft_pad(64 * b * R)] = v[b][fft_bitrev<R>(t)];
+    } else if constexpr (NS % 16 == 0 && NS <= 64) {
+      // k = lane & (NS - 1) is the same for every b; element (lane - k) R + k + (64 b R + t NS), the bracket a multiple of 16
+      const int k = lane & (NS - 1);
+      float2* base = buf + fft_pad((lane - k) * R + k);
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int t = 0; t < R; ++t) base[fft_pad(64 * b * R + t * NS)] = v[b][fft_bitrev<R>(t)];
+    } else if constexpr (NS % 64 == 0 && NS >= 64 * NB) {
+      // lane + 64 b < NS: k = j, element lane + (64 b + t NS)
+      float2* base = buf + fft_pad(lane);
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int t = 0; t < R; ++t) base[fft_pad(64 * b + t * NS)] = v[b][fft_bitrev<R>(t)];
+    } else {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int j = lane + 64 * b, k = j & (NS - 1);
+        const int j0 = (j - k) * R + k;
+#pragma unroll
+        for (int t = 0; t < R; ++t) buf[fft_pad(j0 + t * NS)] = v[b][fft_bitrev<R>(t)];
+      }
     }
   }
 };
