@@ -191,3 +191,30 @@ def test_resident_set_matches_reference_dataset_items(tmp_path, golden, report):
                 worst = max(worst, float(d.max()))
     assert report("resident phase tiles vs reference SpectrogramDataset (rad)", worst, 1e-6)
     report("resident magnitude tiles vs reference SpectrogramDataset (sha256)", 0.0, 0.0)
+
+
+def test_bench_contract_line():
+    """bench.py as the driver runs it (one rank, child process, few steps): exactly one JSON line on stdout with the contract's
+    keys, BASELINE's metric / config, and the `roofline` and `cpu_baseline` objects."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-extras"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["unit"] == "tiles/s" and d["dtype"] == "f32" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert "batch 64" in d["config"]["workload"] and "model" not in d["config"]
+    assert abs(d["value"] - 64 * 1e3 / d["ms_per_step"]) / d["value"] < 1e-3
+    rf, cb = d["roofline"], d["cpu_baseline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert 0.05 < rf["frac"] < 1.0 and rf["kernel"].startswith(("conv_gemm_kernel", "wgrad_", "parity_window"))
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["unit"] == "tiles/s" and cb["sample"]
