@@ -353,6 +353,73 @@ def strong_record(model, dev, world, rank, grad_sync, global_batch=512, steps=6,
             "tiles_per_s": round(global_batch * steps / el, 1), "scaling": "strong"}
 
 
+def launch_children(n_gpus, argv, worker=None, timeout=None):
+    """`python bench.py --gpus N` without a launcher: start N fresh child ranks (one process per GPU; RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT in their environment, exactly what `torch.distributed.run` would set)
+    BEFORE this process has made any GPU call -- it never makes one -- forward rank 0's single JSON line to stdout and
+    everything else to stderr, and return non-zero if any child failed (the others are then terminated by PID).  Nothing is
+    re-exec'd: the children are ordinary subprocesses.  `worker` is the script the ranks run (this file; tests pass a stub)."""
+    import socket
+    import subprocess
+    worker = worker or os.environ.get("SVS_BENCH_WORKER") or os.path.abspath(__file__)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n_gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_gpus), LOCAL_WORLD_SIZE=str(n_gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL across processes needs it on this pool
+        env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // n_gpus)))
+        procs.append(subprocess.Popen([sys.executable, worker, *argv], env=env, stdout=subprocess.PIPE if r == 0 else 2,
+                                      text=True if r == 0 else None))
+    deadline = None if timeout is None else time.monotonic() + timeout
+    failed = None
+    out0 = None
+    pending = set(range(n_gpus))
+    while pending and failed is None:
+        for r in sorted(pending):
+            if r == 0 and out0 is None:
+                try:                                             # drain rank 0's pipe while waiting for it
+                    out0, _ = procs[0].communicate(timeout=0.2)
+                except subprocess.TimeoutExpired:
+                    pass
+            rc = procs[r].poll()
+            if rc is not None:
+                pending.discard(r)
+                if rc != 0:
+                    failed = (r, rc)
+        if deadline is not None and time.monotonic() > deadline:
+            failed = (-1, 124)
+        if pending and failed is None:
+            time.sleep(0.05)
+    if failed is not None:
+        for r in pending:                                        # exact PIDs of the children started above
+            procs[r].terminate()
+        for r in pending:
+            try:
+                procs[r].wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+    if out0 is None:
+        try:
+            out0, _ = procs[0].communicate(timeout=10)
+        except subprocess.TimeoutExpired:
+            procs[0].kill()
+            out0, _ = procs[0].communicate()
+    lines = [ln for ln in (out0 or "").splitlines() if ln.strip()]
+    records = [ln for ln in lines if ln.lstrip().startswith("{")]
+    for ln in lines:
+        if ln not in records[-1:]:
+            sys.stderr.write(ln + "\n")
+    if failed is not None or not records:
+        who = "timed out" if failed and failed[0] < 0 else (f"rank {failed[0]} exited with code {failed[1]}" if failed else "no result line from rank 0")
+        sys.stderr.write(f"bench.py: {n_gpus}-rank run failed ({who})\n")
+        return (failed[1] if failed else 1) or 1
+    print(records[-1], flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -371,8 +438,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_children(args.gpus, sys.argv[1:]))       # no GPU call has been made in this process
+    if not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} of {world} sees no GPU (cuda:{local_rank} of {torch.cuda.device_count()} devices): "
+                         "the benchmark runs the hand-written gfx950 kernels only, there is no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None

@@ -14,7 +14,7 @@ stub is only constructed at train.py:26, never called because the epoch loop is 
 returns hold the reference's own `SpectrogramDataset` and `specific_istft`.  Nothing of the reference's source
 is stored: fixtures are seeds, integer starts, hashes and output arrays.
 
-Usage (build container):  python oracle/gen_golden_train.py [--skip-b64]
+Usage (build container):  python oracle/gen_golden_train.py [--skip-b64] [--batches=128,256,512] [--only-batches]
 """
 from __future__ import annotations
 
@@ -80,9 +80,75 @@ def run_reference_train_script(train_folder: str, work: str):
         os.chdir(cwd)
 
 
+def train_step_golden(B, mask_seed=64):
+    """One L1 train step (train.py:274-283) of the reference's own model at batch B in float64 and float32, default
+    planner inputs (synth.tiles(B), closed-form fresh state, injected dropout masks) -> tests/golden/train_b{B}.npz."""
+    import resource
+    import time
+    model_mod = import_reference_model()
+    mix_np, voc_np = synth.tiles(B)
+    fresh_np = synth.closed_form_state(trained_stats=False)
+    masks_np = synth.dropout_masks(B, seed=mask_seed, step=0)
+    g = {}
+    for dt_name, dt in (("f64", torch.float64), ("f32", torch.float32)):
+        t0 = time.time()
+        mix_t, voc_t = torch.from_numpy(mix_np).to(dt), torch.from_numpy(voc_np).to(dt)
+        refm = ref_model_with(fresh_np, model_mod).to(dt).train()
+        refm.crit = torch.nn.L1Loss()
+        opt = torch.optim.Adam(refm.parameters(), lr=1e-3)
+        masks_t = [torch.from_numpy(m).to(dt) for m in masks_np]
+        for i in range(5):
+            getattr(refm, f"deconv{i + 1}_BAD")[2] = InjectedDropout(masks_t[i])
+        opt.zero_grad()
+        mask = refm(mix_t)                                                     # train.py:274-283, L1 terms
+        loss = refm.crit(mask * mix_t, voc_t) + refm.crit((1 - mask) * mix_t, torch.clamp(mix_t - voc_t, min=0.0))
+        loss.backward()
+        names = [n for n, _ in refm.named_parameters()]
+        grads = {n: p.grad.detach().clone() for n, p in refm.named_parameters()}
+        opt.step()
+        sd = refm.state_dict()
+        if dt is torch.float64 and B <= 64:
+            st_o = uo.to_torch_state(fresh_np, dt)
+            lo, grads_o = uo.train_step(st_o, uo.new_adam_state(st_o), mix_t, voc_t, dropout_masks=masks_t)
+            assert abs(lo - loss.item()) <= 1e-12, (lo, loss.item())
+            for n in names:
+                e = (grads_o[n] - grads[n]).norm().item()
+                assert e <= 1e-9 * max(grads[n].norm().item(), 1e-3), f"oracle grad {n} drifted at B={B}: {e}"
+        p = dt_name + "."
+        g[p + "loss"] = np.array(loss.item(), np.float64)
+        g[p + "mask_stats"] = stats(mask)
+        g[p + "grad_norm"] = np.array([grads[n].double().norm().item() for n in names], np.float64)
+        g[p + "grad_sum"] = np.array([grads[n].double().sum().item() for n in names], np.float64)
+        for n in names:
+            g[p + "grad_sample." + n] = sample(grads[n], 64)
+        if dt is torch.float64:
+            for k in sd:
+                if "running_" in k:
+                    g[p + "buf." + k] = sd[k].to(torch.float32).numpy().copy()
+            for n in ("conv1.0.weight", "conv6.0.weight", "deconv1.weight", "deconv6.weight"):
+                g[p + "param_after." + n] = sample(sd[n], 64)
+        print(f"B={B} {dt_name}: loss {loss.item():.9f}  ({time.time() - t0:.0f} s, peak RSS "
+              f"{resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6:.1f} GB)", flush=True)
+        del refm, opt, mask, loss, grads, sd, mix_t, voc_t
+    g["param_names"] = np.array(names)
+    g["mask_seed"] = np.array(mask_seed, np.int64)
+    np.savez_compressed(os.path.join(OUT, f"train_b{B}.npz"), **g)
+
+
+def batches_from_argv():
+    for arg in sys.argv:
+        if arg.startswith("--batches="):
+            return [int(b) for b in arg.split("=", 1)[1].split(",")]
+    return []
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
+    if "--only-batches" in sys.argv:                 # leave the other fixtures as they are
+        for b in batches_from_argv():
+            train_step_golden(b, mask_seed=b)
+        return
     work = tempfile.mkdtemp(prefix="svs_golden_train_")
     try:
         folder = os.path.join(work, "train")
@@ -157,51 +223,11 @@ def main():
 
     # ---------------------------------------------------------------- train step at B = 64 (BASELINE configs[2])
     if "--skip-b64" not in sys.argv:
-        model_mod = import_reference_model()
-        B = 64
-        mix_np, voc_np = synth.tiles(B)
-        fresh_np = synth.closed_form_state(trained_stats=False)
-        masks_np = synth.dropout_masks(B, seed=64, step=0)
-        g = {}
-        for dt_name, dt in (("f64", torch.float64), ("f32", torch.float32)):
-            mix_t, voc_t = torch.from_numpy(mix_np).to(dt), torch.from_numpy(voc_np).to(dt)
-            refm = ref_model_with(fresh_np, model_mod).to(dt).train()
-            refm.crit = torch.nn.L1Loss()
-            opt = torch.optim.Adam(refm.parameters(), lr=1e-3)
-            masks_t = [torch.from_numpy(m).to(dt) for m in masks_np]
-            for i in range(5):
-                getattr(refm, f"deconv{i + 1}_BAD")[2] = InjectedDropout(masks_t[i])
-            opt.zero_grad()
-            mask = refm(mix_t)                                                     # train.py:274-283, L1 terms
-            loss = refm.crit(mask * mix_t, voc_t) + refm.crit((1 - mask) * mix_t, torch.clamp(mix_t - voc_t, min=0.0))
-            loss.backward()
-            names = [n for n, _ in refm.named_parameters()]
-            grads = {n: p.grad.detach().clone() for n, p in refm.named_parameters()}
-            opt.step()
-            sd = refm.state_dict()
-            if dt is torch.float64:
-                st_o = uo.to_torch_state(fresh_np, dt)
-                lo, grads_o = uo.train_step(st_o, uo.new_adam_state(st_o), mix_t, voc_t, dropout_masks=masks_t)
-                assert abs(lo - loss.item()) <= 1e-12, (lo, loss.item())
-                for n in names:
-                    e = (grads_o[n] - grads[n]).norm().item()
-                    assert e <= 1e-9 * max(grads[n].norm().item(), 1e-3), f"oracle grad {n} drifted at B=64: {e}"
-            p = dt_name + "."
-            g[p + "loss"] = np.array(loss.item(), np.float64)
-            g[p + "mask_stats"] = stats(mask)
-            g[p + "grad_norm"] = np.array([grads[n].double().norm().item() for n in names], np.float64)
-            g[p + "grad_sum"] = np.array([grads[n].double().sum().item() for n in names], np.float64)
-            for n in names:
-                g[p + "grad_sample." + n] = sample(grads[n], 64)
-            if dt is torch.float64:
-                for k in sd:
-                    if "running_" in k:
-                        g[p + "buf." + k] = sd[k].to(torch.float32).numpy().copy()
-                for n in ("conv1.0.weight", "conv6.0.weight", "deconv1.weight", "deconv6.weight"):
-                    g[p + "param_after." + n] = sample(sd[n], 64)
-            print(f"B=64 {dt_name}: loss {loss.item():.9f}")
-        g["param_names"] = np.array(names)
-        np.savez_compressed(os.path.join(OUT, "train_b64.npz"), **g)
+        train_step_golden(64)
+    # ---------------------------------------------------------------- the single-GPU legs of configs[3]: global batch 512 on
+    # 1 / 2 / 4 GPUs is B = 512 / 256 / 128 per GPU (bench.py's strong_b512 record and the driver's strong-scaling runs)
+    for b in batches_from_argv():
+        train_step_golden(b, mask_seed=b)
 
     sizes = {f: os.path.getsize(os.path.join(OUT, f)) for f in sorted(os.listdir(OUT))}
     print("golden fixtures written:", sizes)

@@ -16,7 +16,10 @@ scale, both off by default):
             (torch defaults: center=True, pad_mode="reflect", onesided);
             mag = sqrt(clamp(re^2 + im^2, min=1e-8));
             loss = SpectralConvergence + LogSTFTMagnitude
-               SpectralConvergence = ||y_mag - x_mag||_F / ||y_mag||_F          (norms over the whole batch tensor)
+               SpectralConvergence = mean over the batch of ||y_mag_b - x_mag_b||_F / ||y_mag_b||_F
+                                     (0.4.0: `torch.norm(..., p="fro", dim=[-1, -2])` per item, then `.mean()`; the 0.2.x
+                                      form took ONE ratio of norms over the whole batch tensor -- recalled from the package's
+                                      published source, like everything here: parity unpinned)
                LogSTFTMagnitude    = mean |log(x_mag) - log(y_mag)|            (L1Loss, reduction "mean")
   inputs (B, 1, L) are flattened to (B, L).
 
@@ -43,7 +46,7 @@ def stft_mag(x: torch.Tensor, n_fft: int, hop: int, win: int) -> torch.Tensor:
 
 def stft_loss(x: torch.Tensor, y: torch.Tensor, n_fft: int, hop: int, win: int) -> torch.Tensor:
     xm, ym = stft_mag(x, n_fft, hop, win), stft_mag(y, n_fft, hop, win)
-    sc = torch.norm(ym - xm, p="fro") / torch.norm(ym, p="fro")
+    sc = (torch.norm(ym - xm, p="fro", dim=[-1, -2]) / torch.norm(ym, p="fro", dim=[-1, -2])).mean()
     log_mag = torch.nn.functional.l1_loss(torch.log(xm), torch.log(ym))
     return sc + log_mag
 

@@ -53,7 +53,8 @@ enum SvsTune {
   SVS_TUNE_TRAIN_ONE_STREAM, SVS_TUNE_CONV_PLAN, SVS_TUNE_MFMA_SPLIT, SVS_TUNE_COUNT
 };
 long svs_tune(int key);                       // -1 when unset
-static inline bool svs_tune_on(int key) { return svs_tune(key) >= 0; }
+static inline bool svs_tune_on(int key) { return svs_tune(key) >= 0; }      // VALUED switches: "has been set" (0 is a value)
+static inline bool svs_tune_flag(int key) { return svs_tune(key) > 0; }     // BOOLEAN switches: 0 and -1 both mean off
 
 // geometry of the 5x5 / stride 2 / pad 2 layers (reference model.py:48,79: kernel (5,5), stride (2,2), padding 2)
 static inline int svs_conv_out(int n) { return (n + 1) / 2; }  // floor((n+4-5)/2)+1

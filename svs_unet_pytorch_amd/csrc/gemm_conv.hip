@@ -975,7 +975,7 @@ int svs_conv_gemm_run(int mode, const float* x, long ldx, int B, int H, int W, i
   }
   rc = (mode == MODE_GATHER) ? launch_conv_gemm<MODE_GATHER>(a, pl, stream, skip) : launch_conv_gemm<MODE_PARITY>(a, pl, stream, skip);
   if (rc) return rc;
-  if (pl.ksplit > 1 && !svs_tune_on(SVS_TUNE_SKIP_REDUCE)) {      // (the switch lets bench.py time the GEMM kernel alone)
+  if (pl.ksplit > 1 && !svs_tune_flag(SVS_TUNE_SKIP_REDUCE)) {      // (the switch lets bench.py time the GEMM kernel alone)
     const long total4 = P * N / 4;
     int grid = (int)((total4 + 255) / 256);
     if (grid > 2048) grid = 2048;

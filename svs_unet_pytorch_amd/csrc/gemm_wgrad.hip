@@ -535,7 +535,7 @@ int svs_wgrad_gemm_run(const float* s, long lds, int B, int Hs, int Ws, int Cs, 
     else hipLaunchKernelGGL((wgrad_window_kernel<2>), dim3(wp.gx, wp.gy), dim3(256), 0, stream, wa);
     SVS_CHECK_LAUNCH("wgrad_window");
     pl.ksplit = wp.nslab;
-    if (svs_tune_on(SVS_TUNE_SKIP_REDUCE)) return SVS_OK;
+    if (svs_tune_flag(SVS_TUNE_SKIP_REDUCE)) return SVS_OK;
     return wgrad_reduce_run((const float*)ws, pl.ksplit, Cs, Cl, dw, (float*)ws + (size_t)pl.ksplit * Cs * 25 * Cl, stream);
   }
   WgradArgs a{};
@@ -563,7 +563,7 @@ int svs_wgrad_gemm_run(const float* s, long lds, int B, int Hs, int Ws, int Cs, 
   if (svs_tune(SVS_TUNE_MFMA_SPLIT) > 0) { SVS_WGRAD_LAUNCH(true) } else { SVS_WGRAD_LAUNCH(false) }      // optional mode: mfma_split.h
 #undef SVS_WGRAD_LAUNCH
   SVS_CHECK_LAUNCH("wgrad_gemm");
-  if (svs_tune_on(SVS_TUNE_SKIP_REDUCE)) return SVS_OK;             // lets bench.py time the GEMM kernel alone
+  if (svs_tune_flag(SVS_TUNE_SKIP_REDUCE)) return SVS_OK;             // lets bench.py time the GEMM kernel alone
   return wgrad_reduce_run((const float*)ws, pl.ksplit, Cs, Cl, dw, (float*)ws + (size_t)pl.ksplit * Cs * 25 * Cl, stream);
 }
 

@@ -7,13 +7,16 @@
 // which states the same definition on torch.stft:
 //   three resolutions (n_fft, hop, win_length) = (1024, 120, 600), (2048, 240, 1200), (512, 50, 240); per resolution
 //   X = torch.stft(x, n_fft, hop, win_length, hann_window(win_length), center=True, pad_mode="reflect"),
-//   |X| = sqrt(clamp(re^2 + im^2, min=1e-8));  loss = ||Y| - |X||_F / ||Y||_F  +  mean |log|X| - log|Y||   (w_sc = w_log_mag = 1);
+//   |X| = sqrt(clamp(re^2 + im^2, min=1e-8));  loss = mean_b( ||Y_b| - |X_b||_F / ||Y_b||_F )  +  mean |log|X| - log|Y||
+//   (w_sc = w_log_mag = 1; the spectral-convergence ratio is taken PER WAVEFORM of the batch and averaged, as 0.4.0's
+//   SpectralConvergenceLoss does with norm(dim=[-1, -2]) -- the 0.2.x form took one ratio over the whole batch tensor);
 //   result = mean over the three resolutions.
 //
 // Kernels (one template per n_fft, fft_wave.h transforms, 512-thread blocks = 8 independent waves):
 //   mr_sums_kernel  one wave per frame position: the predicted and the target frame share ONE complex FFT (x in the
 //                   real part, y in the imaginary part); per-block partial sums of (|Y|-|X|)^2, |Y|^2, |log|X|-log|Y||.
-//   mr_finalize     fixed-order double-precision sums -> loss value and the two gradient coefficients per resolution.
+//   mr_finalize     fixed-order double-precision sums -> loss value, the log-magnitude gradient coefficient per resolution and
+//                   the spectral-convergence gradient coefficient per resolution and waveform.
 //   mr_grad_kernel  recomputes the spectra (cheaper than storing 12 bytes per bin), forms dL/dX, and brings TWO frames
 //                   back with one inverse FFT (Hermitian-extended spectra of frames t, t+1 in the real / imaginary part);
 //                   the windowed frame gradients go to a frame buffer.
@@ -43,7 +46,7 @@ struct MrArgs {
   const float* x; const float* y; int B; long L;     // predicted / target waveforms (B, L)
   int hop, win, F;                                   // this resolution: hop, window length, frames = 1 + L / hop
   float* partial;                                    // [B * gridDim.x][3]
-  const float* coef;                                 // [2]: SC and log-magnitude gradient coefficients (device)
+  const float* coef;                                 // [1 + B]: log-magnitude coefficient, then the SC coefficient of every waveform (device)
   float* frames;                                     // [B][F][win] windowed frame gradients (the window's support only)
 };
 
@@ -118,35 +121,42 @@ __global__ __launch_bounds__(64 * MrCfg<N>::WAVES) void mr_sums_kernel(MrArgs p)
 }
 
 struct MrFinalArgs {
-  const float* partial[MR_NRES]; int nblk[MR_NRES]; double count[MR_NRES];
-  float grad_scale; float* loss; float* coef;        // coef: [MR_NRES][2]
+  const float* partial[MR_NRES]; int gx[MR_NRES]; double count[MR_NRES];        // partial[r]: [B][gx[r]][3]
+  int B; float grad_scale; float* loss; float* coef[MR_NRES];                   // coef[r]: [1 + B]
 };
+// One wave per waveform (16 waves walk b = wave, wave + 16, ...): the lanes sum that waveform's gx block partials, lane 0 forms
+// its spectral-convergence ratio and gradient coefficient and keeps the wave's running sums; thread 0 adds the 16 waves'
+// sums in a fixed order.  Everything in double, every order fixed: bitwise reproducible.
 __global__ __launch_bounds__(1024) void mr_finalize_kernel(MrFinalArgs a) {
-  __shared__ double sh[MR_NRES][3][16];
+  __shared__ double sh[MR_NRES][2][16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int r = 0; r < MR_NRES; ++r) {
-    double s[3] = {0.0, 0.0, 0.0};
-    for (int i = tid; i < a.nblk[r]; i += 1024)
-      for (int j = 0; j < 3; ++j) s[j] += (double)a.partial[r][(long)i * 3 + j];
-    for (int j = 0; j < 3; ++j) {
-      for (int o = 32; o > 0; o >>= 1) s[j] += __shfl_xor(s[j], o, 64);
-      if (lane == 0) sh[r][j][wave] = s[j];
+    double ratio_sum = 0.0, log_sum = 0.0;
+    for (int b = wave; b < a.B; b += 16) {
+      double s[3] = {0.0, 0.0, 0.0};
+      const float* pb = a.partial[r] + (long)b * a.gx[r] * 3;
+      for (int i = lane; i < a.gx[r]; i += 64)
+        for (int j = 0; j < 3; ++j) s[j] += (double)pb[(long)i * 3 + j];
+      for (int j = 0; j < 3; ++j)
+        for (int o = 32; o > 0; o >>= 1) s[j] += __shfl_xor(s[j], o, 64);
+      if (lane == 0) {
+        const double nd = sqrt(s[0]), ny = sqrt(s[1]);
+        ratio_sum += ny > 0.0 ? nd / ny : 0.0;
+        log_sum += s[2];
+        // d/d|X_b| of  (1/B) ||Y_b|-|X_b||_F / ||Y_b||_F  is  -(|Y_b|-|X_b|) / (B ||Y_b|-|X_b||_F ||Y_b||_F)
+        a.coef[r][1 + b] = (nd > 0.0 && ny > 0.0) ? (float)((double)a.grad_scale / (MR_NRES * (double)a.B * nd * ny)) : 0.f;
+      }
     }
+    if (lane == 0) { sh[r][0][wave] = ratio_sum; sh[r][1][wave] = log_sum; }
   }
   __syncthreads();
   if (tid == 0) {
     double total = 0.0;
     for (int r = 0; r < MR_NRES; ++r) {
-      double s[3];
-      for (int j = 0; j < 3; ++j) {
-        s[j] = 0.0;
-        for (int w = 0; w < 16; ++w) s[j] += sh[r][j][w];
-      }
-      const double nd = sqrt(s[0]), ny = sqrt(s[1]);
-      total += (ny > 0.0 ? nd / ny : 0.0) + s[2] / a.count[r];
-      // d/d|X| of  ||Y|-|X||_F / ||Y||_F  is  -(|Y|-|X|) / (||Y|-|X||_F ||Y||_F);  of the mean log distance  sign / (count |X|)
-      a.coef[r * 2] = (nd > 0.0 && ny > 0.0) ? (float)((double)a.grad_scale / (MR_NRES * nd * ny)) : 0.f;
-      a.coef[r * 2 + 1] = (float)((double)a.grad_scale / (MR_NRES * a.count[r]));
+      double ratio = 0.0, lg = 0.0;
+      for (int w = 0; w < 16; ++w) { ratio += sh[r][0][w]; lg += sh[r][1][w]; }
+      total += ratio / (double)a.B + lg / a.count[r];
+      a.coef[r][0] = (float)((double)a.grad_scale / (MR_NRES * a.count[r]));      // of the mean log distance: sign / (count |X|)
     }
     a.loss[0] = (float)(total / MR_NRES);
   }
@@ -164,7 +174,7 @@ __global__ __launch_bounds__(64 * MrCfg<N>::WAVES) void mr_grad_kernel(MrArgs p)
   __syncthreads();
   if (ta >= p.F) return;                             // (no barriers below: waves are independent)
   float2* const buf = fbuf + wave * BUF;
-  const float csc = p.coef[0], clog = p.coef[1];
+  const float clog = p.coef[0], csc = p.coef[1 + b];
   float2 H[2][NR];                                   // Hermitian-weighted dL/dX of frames ta, ta + 1
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
@@ -190,6 +200,7 @@ __global__ __launch_bounds__(64 * MrCfg<N>::WAVES) void mr_grad_kernel(MrArgs p)
       }
       H[h][r] = g;
     }
+    fft_wave_sync();                                 // every lane has read this frame's spectra before the buffer is refilled
   }
   // conj(Z), Z = Ha + i Hb extended Hermitian; forward transform -> conj(ifft(Z)) = ga - i gb
 #pragma unroll
@@ -260,7 +271,7 @@ static MrWs mr_layout(int B, long L, void* ws) {
   char* base = (char*)ws;
   size_t used = 0;
   auto take = [&](size_t nfloats) { float* p = base ? (float*)(base + used) : nullptr; used += svs_align_up(nfloats * 4, 256); return p; };
-  w.coef = take(2 * MR_NRES);
+  w.coef = take((size_t)MR_NRES * (1 + B));
   for (int r = 0; r < MR_NRES; ++r) {
     const int F = (int)(1 + L / MR_HOP[r]);
     w.nblk[r] = B * ((F + mr_waves(MR_NFFT[r]) - 1) / mr_waves(MR_NFFT[r]));
@@ -299,14 +310,14 @@ extern "C" int svs_mrstft_loss_fwd_bwd(const float* x, const float* y, int B, in
   MrArgs a[MR_NRES];
   MrFinalArgs f{};
   for (int r = 0; r < MR_NRES; ++r) {
-    a[r] = MrArgs{x, y, B, (long)L, MR_HOP[r], MR_WIN[r], (int)(1 + L / MR_HOP[r]), w.partial[r], w.coef + 2 * r, w.frames[r]};
+    a[r] = MrArgs{x, y, B, (long)L, MR_HOP[r], MR_WIN[r], (int)(1 + L / MR_HOP[r]), w.partial[r], w.coef + (size_t)r * (1 + B), w.frames[r]};
     rc = MR_NFFT[r] == 1024 ? mr_launch<1024>(false, a[r], B, stream) : MR_NFFT[r] == 2048 ? mr_launch<2048>(false, a[r], B, stream)
                                                                                               : mr_launch<512>(false, a[r], B, stream);
     if (rc) return rc;
-    f.partial[r] = w.partial[r]; f.nblk[r] = w.nblk[r];
+    f.partial[r] = w.partial[r]; f.gx[r] = w.nblk[r] / B; f.coef[r] = w.coef + (size_t)r * (1 + B);
     f.count[r] = (double)B * a[r].F * (MR_NFFT[r] / 2 + 1);
   }
-  f.grad_scale = grad_scale; f.loss = loss; f.coef = w.coef;
+  f.B = B; f.grad_scale = grad_scale; f.loss = loss;
   hipLaunchKernelGGL(mr_finalize_kernel, dim3(1), dim3(1024), 0, stream, f);
   SVS_CHECK_LAUNCH("mr_finalize");
   if (!d_x) return SVS_OK;

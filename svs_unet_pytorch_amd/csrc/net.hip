@@ -12,6 +12,7 @@
 // Training additionally keeps the pre-BatchNorm ("raw") output of every block, the batch statistics,
 // both weight packings, and gradient images dcat[k] / dc6 of the same shapes.
 #include <math.h>
+#include <atomic>
 #include <mutex>
 #include <stdarg.h>
 #include <stdlib.h>
@@ -37,30 +38,30 @@ extern "C" const char* svs_last_error_string(void) { return g_err; }
 static const char* const TUNE_NAMES[SVS_TUNE_COUNT] = {
     "CONV_CFG", "CONV_KSPLIT", "CONV_WINDOW", "CONV_SKIP", "CONV_KORDER", "CONV_DIRECT", "SKIP_REDUCE", "WGRAD_CFG",
     "WGRAD_KSPLIT", "WGRAD_SKIP", "WGRAD_WINDOW", "WGRAD_C1_VALU", "SIDE_PRIORITY", "TRAIN_UNFUSED", "TRAIN_ONE_STREAM", "CONV_PLAN", "MFMA_SPLIT"};
-static long g_tune[SVS_TUNE_COUNT];
+static std::atomic<long> g_tune[SVS_TUNE_COUNT];      // written by svs_tuning_set while compute threads read: relaxed atomics
 static std::once_flag g_tune_once;
 static void tune_load_env() {
   for (int k = 0; k < SVS_TUNE_COUNT; ++k) {
     char name[64];
     snprintf(name, sizeof(name), "SVS_%s", TUNE_NAMES[k]);
     const char* e = getenv(name);
-    g_tune[k] = e ? (*e ? atol(e) : 1) : -1;
+    g_tune[k].store(e ? (*e ? atol(e) : 1) : -1, std::memory_order_relaxed);
   }
 }
 long svs_tune(int key) {
   std::call_once(g_tune_once, tune_load_env);
-  return (key >= 0 && key < SVS_TUNE_COUNT) ? g_tune[key] : -1;
+  return (key >= 0 && key < SVS_TUNE_COUNT) ? g_tune[key].load(std::memory_order_relaxed) : -1;
 }
 extern "C" int svs_tuning_set(const char* name, long value) {
   std::call_once(g_tune_once, tune_load_env);
   SVS_REQUIRE(name, "svs_tuning_set: null name");
   if (!strcmp(name, "*")) {                 // every switch: value -1 = back to the process defaults (the SVS_<NAME> environment)
     if (value == -1) tune_load_env();
-    else for (int k = 0; k < SVS_TUNE_COUNT; ++k) g_tune[k] = value;
+    else for (int k = 0; k < SVS_TUNE_COUNT; ++k) g_tune[k].store(value, std::memory_order_relaxed);
     return SVS_OK;
   }
   for (int k = 0; k < SVS_TUNE_COUNT; ++k)
-    if (!strcmp(name, TUNE_NAMES[k])) { g_tune[k] = value; return SVS_OK; }
+    if (!strcmp(name, TUNE_NAMES[k])) { g_tune[k].store(value, std::memory_order_relaxed); return SVS_OK; }
   svs_set_error("svs_tuning_set: unknown switch '%s'", name);
   return SVS_ERR_INVALID;
 }
@@ -491,8 +492,8 @@ static int train_forward_impl(const ParamView& v, float* bn_buffers, int64_t* nb
                               const Geo& g, const TrainWs& t, float* mask, hipStream_t stream) {
   const int B = g.B;
   int rc;
-  const int fused_rows = svs_tune_on(SVS_TUNE_TRAIN_UNFUSED) ? 0 : (int)(t.bnws_bytes / sizeof(float));     // capacity (floats) for fused BatchNorm partials; A/B switch
-  SideStream* sd = svs_tune_on(SVS_TUNE_TRAIN_ONE_STREAM) ? nullptr : side_stream(stream);          // A/B switch
+  const int fused_rows = svs_tune_flag(SVS_TUNE_TRAIN_UNFUSED) ? 0 : (int)(t.bnws_bytes / sizeof(float));     // capacity (floats) for fused BatchNorm partials; A/B switch
+  SideStream* sd = svs_tune_flag(SVS_TUNE_TRAIN_ONE_STREAM) ? nullptr : side_stream(stream);          // A/B switch
   std::unique_lock<std::mutex> guard;
   if (sd) guard = std::unique_lock<std::mutex>(sd->mu);
   // weight packings for this step (weights change every optimiser step)
@@ -578,8 +579,8 @@ static int train_backward_impl(const ParamView& v, float* grads, const float* mi
   int rc;
   auto G = [&](int idx) { return grads + svs_unet_param_offset(idx); };
   SvsSumJobs sums{};                         // bias-gradient reductions, run as one batched launch per half
-  const bool unfused = svs_tune_on(SVS_TUNE_TRAIN_UNFUSED);     // A/B switch: one launch per reduction, as before
-  SideStream* sd = svs_tune_on(SVS_TUNE_TRAIN_ONE_STREAM) ? nullptr : side_stream(stream);   // A/B switch: everything on `stream`
+  const bool unfused = svs_tune_flag(SVS_TUNE_TRAIN_UNFUSED);     // A/B switch: one launch per reduction, as before
+  SideStream* sd = svs_tune_flag(SVS_TUNE_TRAIN_ONE_STREAM) ? nullptr : side_stream(stream);   // A/B switch: everything on `stream`
   std::unique_lock<std::mutex> guard;
   if (sd) guard = std::unique_lock<std::mutex>(sd->mu);
   const hipStream_t wstream = sd ? sd->s : stream;                  // where the weight gradients run
@@ -673,7 +674,7 @@ static int train_backward_impl(const ParamView& v, float* grads, const float* mi
 }
 
 extern "C" int svs_unet_train_bwd_sync(hipStream_t consumer) {
-  SideStream* sd = svs_tune_on(SVS_TUNE_TRAIN_ONE_STREAM) ? nullptr : side_stream(consumer);
+  SideStream* sd = svs_tune_flag(SVS_TUNE_TRAIN_ONE_STREAM) ? nullptr : side_stream(consumer);
   if (!sd) return SVS_OK;
   std::lock_guard<std::mutex> guard(sd->mu);
   SVS_HIP(hipEventRecord(sd->sync, sd->s));

@@ -482,7 +482,7 @@ int svs_wgrad_c1_run(const float* s, long lds, int B, int Hs, int Ws, int Cs, co
   WgC1Args a{s, lds, B, Hs, Ws, l, Hl, Wl, (float*)ws, (P + nb - 1) / nb, half};
   int nslab = nb;
   const int ntiles = B * ((Hs + 3) / 4) * ((Ws + 15) / 16);
-  if (ntiles >= 256 && !svs_tune_on(SVS_TUNE_WGRAD_C1_VALU)) {          // MFMA kernel: one slab per wave, <= 1024 waves (workspace bound)
+  if (ntiles >= 256 && !svs_tune_flag(SVS_TUNE_WGRAD_C1_VALU)) {          // MFMA kernel: one slab per wave, <= 1024 waves (workspace bound)
     int waves = ntiles < 1024 ? ntiles : 1024;
     waves = (waves + 3) / 4 * 4;
     if (waves > 1024) waves = 1024;

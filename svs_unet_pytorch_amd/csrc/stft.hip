@@ -151,6 +151,7 @@ __global__ __launch_bounds__(512) void stft_fwd_kernel(StftArgs p) {
     A[r] = float2{0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y)};
     B[r] = float2{0.5f * (zk.y + zn.y), 0.5f * (zn.x - zk.x)};
   }
+  fft_wave_sync();                                          // every lane has read Z before the buffer is rewritten below
   float vmax = 0.f;
 #pragma unroll
   for (int r = 0; r < 9; ++r) {
@@ -339,6 +340,7 @@ __global__ __launch_bounds__(512, 2) void istft_kernel(IstftArgs p, int ngroups)
     Sb[r] = float2{m.y * qb.x, edge ? 0.f : m.y * qb.y};
   }
   // conj(Z) with Z = Sa + i Sb (Hermitian-extended): the forward transform of conj(Z) is conj(ifft(Z)) = a - i b
+  fft_wave_sync();                                          // every lane has read its staged values before the buffer is refilled
 #pragma unroll
   for (int r = 0; r < 9; ++r) {
     const int k = lane + 64 * r;
@@ -388,6 +390,139 @@ __global__ __launch_bounds__(512, 2) void istft_kernel(IstftArgs p, int ngroups)
     }
   }
   if (p.absmax_partial) {                                   // partial[c][group]: max |y| of this block
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+    __syncthreads();
+    if (lane == 0) raw[wave] = vmax;
+    __syncthreads();
+    if (tid == 0) {
+      float m = raw[0];
+      for (int w = 1; w < NW; ++w) m = fmaxf(m, raw[w]);
+      p.absmax_partial[g] = m;
+    }
+  }
+}
+
+// General overlap-add for ANY 0 < hop <= n_fft (data.py:24-25 lets --hop_size override the config, and config.py:14-25 records
+// runs at HOP_SIZE = 256: four frames per sample).  A block owns G hops = G * hop padded samples of one channel and walks the
+// frames that touch them, floor((n_fft - 1) / hop) + G of them, in rounds of 16 (two per wave, the same transform as above);
+// after each round every thread adds the round's frames into ITS OWN positions of an LDS accumulator (windowed sample and
+// squared window side by side: fixed frame order, no atomics), and after the last round divides and stores.  Slower than the
+// two-frames-per-sample kernel (one block per CU, divisions per position and round); that one keeps hop >= n_fft / 2.
+template <int PMODE>
+__global__ __launch_bounds__(512) void istft_general_kernel(IstftArgs p, int ngroups, int G, int rounds) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int BUF = FftSize<NFFT>::BUF, TW = FftSize<NFFT>::TW, NW = 8, NF = 2 * NW;
+  constexpr int NIT = (NBIN * NF + 511) / 512;
+  float2* const fbuf = (float2*)smem;                       // [8][BUF]
+  float2* const tw = fbuf + NW * BUF;
+  float2* const acc = tw + TW;                              // [G * hop]: (sum of windowed samples, sum of squared windows)
+  float* const raw = (float*)fbuf;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = blockIdx.x, c = g / ngroups, t0 = (g - c * ngroups) * G;      // padded samples [hop * t0, hop * (t0 + G))
+  const int seg_len = G * p.hop, halo = (NFFT - 1) / p.hop;
+  float2* const buf = fbuf + wave * BUF;
+  constexpr unsigned OOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t rmag = __builtin_amdgcn_make_buffer_rsrc((void*)p.mag, 0, OOB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rmask = __builtin_amdgcn_make_buffer_rsrc((void*)(p.mask ? p.mask : p.mag), 0, OOB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rph = __builtin_amdgcn_make_buffer_rsrc((void*)p.phase, 0, OOB, 0x00020000);
+  const bool has_mask = p.mask != nullptr;
+  fft_build_twiddles<NFFT>(tw, tid, 512);
+  for (int i = tid; i < seg_len; i += 512) acc[i] = float2{0.f, 0.f};
+  for (int r = 0; r < rounds; ++r) {
+    const int tb = t0 - halo + NF * r;                      // first frame of this round
+    __syncthreads();                                        // the previous round's buffers have been consumed (and, r = 0: twiddles)
+    // ---- stage: this thread's frame column (16 frames x 513 bins through the waves' buffers, as in istft_kernel)
+    {
+      const int tf = tb + (tid & (NF - 1));
+      const bool tok = tf >= 0 && tf < p.T;
+      const unsigned cbase = tok ? (unsigned)p.lay.col(c, tf) : 0u;
+      for (int it = 0; it < NIT; ++it) {
+        const int k = (tid >> 4) + (512 / NF) * it;
+        if (k >= NBIN) continue;
+        const bool ok = tok && k >= p.lay.first_bin;
+        const unsigned off = ok ? (cbase + (unsigned)(k * p.lay.seg)) * 4u : OOB;
+        float m = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rmag, (int)off, 0, 0));
+        if (has_mask) {
+          const float mk = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rmask, (int)off, 0, 0));
+          m *= p.invert ? 1.f - mk : mk;
+        }
+        const int f = tid & (NF - 1), w = f >> 1, at = 2 * (w * BUF + k + w) + (f & 1);
+        raw[at] = m;
+        if (PMODE == 3) raw[at + BUF] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rph, (int)off, 0, 0));
+      }
+    }
+    __syncthreads();
+    // ---- spectra of this wave's two frames, Hermitian-extended conj(Sa + i Sb), one transform
+    const int ta = tb + 2 * wave;
+    float2 Sa[9], Sb[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      const int k = lane + 64 * q;
+      Sa[q] = Sb[q] = float2{0.f, 0.f};
+      if (k > NFFT / 2) continue;
+      const float2 m = buf[k + wave];
+      float2 qa, qb;
+      if (PMODE == 3) {
+        const float2 a = buf[k + wave + BUF / 2];
+        const float ra = a.x * 0.15915494309189535f, rb = a.y * 0.15915494309189535f;
+        qa = float2{__builtin_amdgcn_cosf(ra), __builtin_amdgcn_sinf(ra)};
+        qb = float2{__builtin_amdgcn_cosf(rb), __builtin_amdgcn_sinf(rb)};
+      } else {
+        struct F2 { float x, y; };
+        const bool oka = ta >= 0 && ta < p.T, okb = ta + 1 >= 0 && ta + 1 < p.T;
+        const unsigned oa = oka ? (unsigned)(((long)c * p.T + ta) * NBIN + k) * 8u : OOB;
+        const unsigned ob = okb ? (unsigned)(((long)c * p.T + ta + 1) * NBIN + k) * 8u : OOB;
+        const F2 va = __builtin_bit_cast(F2, __builtin_amdgcn_raw_buffer_load_b64(rph, (int)oa, 0, 0));
+        const F2 vb = __builtin_bit_cast(F2, __builtin_amdgcn_raw_buffer_load_b64(rph, (int)ob, 0, 0));
+        qa = float2{va.x, va.y};
+        qb = float2{vb.x, vb.y};
+      }
+      const bool edge = (k == 0 || k == NFFT / 2);
+      Sa[q] = float2{m.x * qa.x, edge ? 0.f : m.x * qa.y};
+      Sb[q] = float2{m.y * qb.x, edge ? 0.f : m.y * qb.y};
+    }
+    fft_wave_sync();                                        // every lane has read its staged values before the buffer is refilled
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      const int k = lane + 64 * q;
+      if (k > NFFT / 2) continue;
+      buf[fft_pad(k)] = float2{Sa[q].x - Sb[q].y, -(Sa[q].y + Sb[q].x)};
+      if (k > 0 && k < NFFT / 2) buf[fft_pad(NFFT - k)] = float2{Sa[q].x + Sb[q].y, -(Sb[q].x - Sa[q].y)};
+    }
+    fft_wave<NFFT>(buf, tw, lane);
+    __syncthreads();
+    // ---- accumulate: position i (padded sample hop * t0 + i) takes every frame of this round that covers it, ascending
+    for (int i = tid; i < seg_len; i += 512) {
+      const int q = p.hop * t0 + i;
+      int lo = q - (NFFT - 1);
+      lo = lo <= 0 ? 0 : (int)((unsigned)(lo + p.hop - 1) / (unsigned)p.hop);
+      int hi = (int)((unsigned)q / (unsigned)p.hop);
+      if (hi > p.T - 1) hi = p.T - 1;
+      if (lo < tb) lo = tb;
+      if (hi > tb + NF - 1) hi = tb + NF - 1;
+      float2 a = acc[i];
+      for (int t = lo; t <= hi; ++t) {
+        const int f = t - tb, m = q - t * p.hop;
+        const float2 z = fbuf[(f >> 1) * BUF + fft_pad(m)];
+        const float w = hann_fast(m);
+        a.x += ((f & 1) ? -z.y : z.x) * (w * (1.0f / NFFT));
+        a.y += w * w;
+      }
+      acc[i] = a;
+    }
+  }
+  // ---- divide by the window envelope, store, |.|max
+  float vmax = 0.f;
+  for (int i = tid; i < seg_len; i += 512) {
+    const long e = (long)p.hop * t0 + i - NFFT / 2;
+    if (e < 0 || e >= p.n_out) continue;
+    const float2 a = acc[i];
+    const float v = a.y > 1.1754944e-38f ? a.x * __builtin_amdgcn_rcpf(a.y) : a.x;
+    p.y[(long)c * p.n_out + e] = v;
+    vmax = fmaxf(vmax, fabsf(v));
+  }
+  if (p.absmax_partial) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
     __syncthreads();
@@ -464,8 +599,20 @@ extern "C" int svs_stft_fwd(const float* y, int64_t n_samples, int n_fft, int ho
   return svs_stft_tiles(y, n_samples, 1, n_fft, hop, mag, (int64_t)NBIN * T, T, NBIN, 0, T, phase, phase ? 2 : 0, nullptr, stream);
 }
 
-// padded length n_fft + hop * (T - 1): the last samples belong to group floor((padded - 1) / (15 hop))
-static int svs_istft_groups_per_channel(int hop, int frames) { return (int)((NFFT + (long)hop * (frames - 1) + (long)IGROUP * hop - 1) / ((long)IGROUP * hop)); }
+// hops per block and rounds of 16 frames of the general kernel: G + floor((n_fft - 1) / hop) frames touch G hops; one round
+// while the halo leaves at least 4 hops of it (hop >= 86), else enough rounds that at least half of every round is new hops
+static void istft_general_plan(int hop, int* G, int* rounds) {
+  const int halo = (NFFT - 1) / hop;
+  *rounds = halo <= 12 ? 1 : (halo + 7) / 8;
+  *G = 16 * *rounds - halo;
+}
+// padded length n_fft + hop * (T - 1): the last samples belong to group floor((padded - 1) / (G hop)), G = 15 hops per block
+// of the two-frames-per-sample kernel (hop >= n_fft / 2), istft_general_plan's below it
+static int svs_istft_groups_per_channel(int hop, int frames) {
+  int G = IGROUP, rounds;
+  if (hop < NFFT / 2) istft_general_plan(hop, &G, &rounds);
+  return (int)((NFFT + (long)hop * (frames - 1) + (long)G * hop - 1) / ((long)G * hop));
+}
 // blocks per channel of svs_istft_tiles = absmax partials per channel (layout [channel][group])
 extern "C" int svs_istft_groups(int hop, int frames, int channels) { (void)channels; return svs_istft_groups_per_channel(hop, frames); }
 
@@ -474,7 +621,7 @@ extern "C" int svs_istft_tiles(const float* mag, int64_t chan_stride, int seg, i
                                float* absmax_partial, hipStream_t stream) {
   SVS_REQUIRE(mag && phase && y && hop > 0 && frames > 1 && channels > 0, "svs_istft_tiles: bad arguments (need >= 2 frames)");
   SVS_REQUIRE(n_fft == NFFT, "svs_istft_tiles: only n_fft=1024 (reference config.py:47) is built, got %d", n_fft);
-  SVS_REQUIRE(hop <= NFFT && hop >= NFFT / 2, "svs_istft_tiles: hop %d outside [n_fft/2, n_fft] (a sample may be covered by at most two frames)", hop);
+  SVS_REQUIRE(hop <= NFFT, "svs_istft_tiles: hop %d > n_fft leaves samples that no frame covers", hop);
   SVS_REQUIRE(phase_mode == 1 || phase_mode == 3, "svs_istft_tiles: phase_mode must be 1 (frame-major phasors) or 3 (angles)");
   SVS_REQUIRE((long)channels * (chan_stride > (long)frames * NBIN ? chan_stride : (long)frames * NBIN) * 8 < (1L << 31),
               "svs_istft_tiles: a spectrogram view of more than 2 GiB needs 64-bit offsets; split the channels");
@@ -485,11 +632,21 @@ extern "C" int svs_istft_tiles(const float* mag, int64_t chan_stride, int seg, i
   a.mask = mask; a.invert = invert; a.phase = phase; a.phase_mode = phase_mode;
   a.channels = channels; a.T = frames; a.hop = hop; a.y = y; a.n_out = (long)hop * (frames - 1);
   a.absmax_partial = absmax_partial;
-  const size_t lds = inv_lds_bytes();
-  if ((rc = phase_mode == 1 ? allow_lds(istft_kernel<1>, lds) : allow_lds(istft_kernel<3>, lds))) return rc;
   const int ngroups = svs_istft_groups_per_channel(hop, frames);
   const long total = (long)ngroups * channels;
   const dim3 grid((unsigned)total);
+  if (hop < NFFT / 2) {                          // more than two frames per sample: the general overlap-add
+    int G, rounds;
+    istft_general_plan(hop, &G, &rounds);
+    const size_t lds = inv_lds_bytes() + (size_t)G * hop * 8;
+    if ((rc = phase_mode == 1 ? allow_lds(istft_general_kernel<1>, lds) : allow_lds(istft_general_kernel<3>, lds))) return rc;
+    if (phase_mode == 1) hipLaunchKernelGGL(istft_general_kernel<1>, grid, dim3(512), lds, stream, a, ngroups, G, rounds);
+    else hipLaunchKernelGGL(istft_general_kernel<3>, grid, dim3(512), lds, stream, a, ngroups, G, rounds);
+    SVS_CHECK_LAUNCH("istft_general");
+    return SVS_OK;
+  }
+  const size_t lds = inv_lds_bytes();
+  if ((rc = phase_mode == 1 ? allow_lds(istft_kernel<1>, lds) : allow_lds(istft_kernel<3>, lds))) return rc;
   if (phase_mode == 1) hipLaunchKernelGGL(istft_kernel<1>, grid, dim3(512), lds, stream, a, ngroups);
   else hipLaunchKernelGGL(istft_kernel<3>, grid, dim3(512), lds, stream, a, ngroups);
   SVS_CHECK_LAUNCH("istft");

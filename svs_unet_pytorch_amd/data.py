@@ -221,6 +221,11 @@ def main(argv=None):
     parser.add_argument("--sr", type=int, default=SAMPLE_RATE)
     parser.add_argument("--direction", default="to_spec", choices=["to_spec", "to_wave"])
     args = parser.parse_args(argv)
+    if args.win_size != WINDOW_SIZE:             # data.py:24 lets it vary; the gfx950 transforms are built for the config's 1024 only
+        parser.error(f"--win_size {args.win_size}: the STFT / iSTFT kernels are built for n_fft = {WINDOW_SIZE} (config.WINDOW_SIZE) only; "
+                     "--hop_size may be anything in 1..win_size")
+    if not 0 < args.hop_size <= args.win_size:
+        parser.error(f"--hop_size {args.hop_size}: must be in 1..{args.win_size} (a larger hop leaves samples that no frame covers)")
     if not torch.cuda.is_available():
         print("data.py needs a ROCm device (the STFT/iSTFT are gfx950 kernels, no CPU path).")
         sys.exit(1)

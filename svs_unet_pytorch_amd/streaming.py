@@ -62,12 +62,14 @@ def separate_waveform(model, y: torch.Tensor, vocal_solo: bool = True, n_fft: in
     flat = tiles.view(C * n_tiles, 1, tiles.shape[3], tiles.shape[4])
     mask = torch.empty_like(flat)
     was_training, was_precision = model.training, model.eval_precision
-    model.eval()
-    if precision is not None:                                    # "bf16": the convolutions run on the bf16 MFMA (configs[4])
-        model.eval_precision = precision
-    for s in range(0, flat.shape[0], max_batch):
-        mask[s:s + max_batch] = model(flat[s:s + max_batch])
-    model.eval_precision = was_precision
-    model.train(was_training)
+    try:
+        model.eval()
+        if precision is not None:                                # "bf16": the convolutions run on the bf16 MFMA (configs[4])
+            model.eval_precision = precision
+        for s in range(0, flat.shape[0], max_batch):
+            mask[s:s + max_batch] = model(flat[s:s + max_batch])
+    finally:                                                     # a failing forward must not leave the model in another mode
+        model.eval_precision = was_precision
+        model.train(was_training)
     out = istft_from_tiles(tiles, mask, phase, T, invert=not vocal_solo, n_fft=n_fft, hop=hop, peak=peak)
     return out[0] if squeeze else out

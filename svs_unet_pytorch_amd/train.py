@@ -39,8 +39,9 @@ from .model import ALPHA_L1, ALPHA_MR, UNet
 class SpectrogramDataset(Data.Dataset):
     """train.py:65-143.  Returns (mix, voc, mix_phase, voc_phase), each float32 (1, 512, INPUT_LEN)."""
 
-    def __init__(self, path, samples_per_song=SAMPLES_PER_SONG):
+    def __init__(self, path, samples_per_song=SAMPLES_PER_SONG, with_phase=True):
         self.path = path
+        self.with_phase = with_phase          # False: L1-only objective or a set without *_phase.npy -> empty phase tensors
         self.mixture_path = os.path.join(path, "mixture")
         self.vocal_path = os.path.join(path, "vocal")
         self.samples_per_song = samples_per_song
@@ -58,8 +59,11 @@ class SpectrogramDataset(Data.Dataset):
         pname = name.replace("_spec.npy", "_phase.npy")
         mix = np.load(os.path.join(self.mixture_path, name))[1:, :]                      # drop the DC row (train.py:109-112)
         voc = np.load(os.path.join(self.vocal_path, name))[1:, :]
-        mix_phase = np.angle(np.load(os.path.join(self.mixture_path, pname))).astype(np.float32)[1:, :]
-        voc_phase = np.angle(np.load(os.path.join(self.vocal_path, pname))).astype(np.float32)[1:, :]
+        if self.with_phase:
+            mix_phase = np.angle(np.load(os.path.join(self.mixture_path, pname))).astype(np.float32)[1:, :]
+            voc_phase = np.angle(np.load(os.path.join(self.vocal_path, pname))).astype(np.float32)[1:, :]
+        else:                                                                             # same crop / pad arithmetic on nothing
+            mix_phase = voc_phase = np.zeros((0, mix.shape[1]), np.float32)
         target, cur = INPUT_LEN, mix.shape[1]
         if cur > target:
             start = random.randint(0, cur - target)                                       # shared start (train.py:121)
@@ -71,6 +75,10 @@ class SpectrogramDataset(Data.Dataset):
             mix_phase, voc_phase = np.pad(mix_phase, pad), np.pad(voc_phase, pad)
         as_t = lambda a: torch.from_numpy(np.ascontiguousarray(a[np.newaxis], dtype=np.float32))
         return as_t(mix), as_t(voc), as_t(mix_phase), as_t(voc_phase)
+
+    def has_phase_files(self):
+        pname = lambda n: n.replace("_spec.npy", "_phase.npy")
+        return all(os.path.exists(os.path.join(d, pname(n))) for n in self.file_names for d in (self.mixture_path, self.vocal_path))
 
 
 def epoch_order(n, shuffle=True, rank=0, world=1, epoch=0):
@@ -269,9 +277,16 @@ def main(argv=None):
 
     # objective: the reference's alpha_L1 * L1 + alpha_MR * MR-STFT (train.py:296) unless SVS_OBJECTIVE=l1 or no phases
     full = os.environ.get("SVS_OBJECTIVE", "full") != "l1"
-    if full and resident is not None and not resident.has_phase:
+    if full and not (resident.has_phase if resident is not None else train_dataset.has_phase_files()):
         print("Warning: no *_phase.npy files next to the spectrograms -- training on the L1 terms only.")
         full = False
+    # the CPU-side datasets load phase files only when the objective needs them (and they exist): the L1-only fallback
+    # holds for the validation loop and the SVS_DATA_LOADER=cpu path too, not just for the resident loader
+    train_dataset.with_phase = full
+    if valid_loader is not None:
+        valid_dataset.with_phase = full and valid_dataset.has_phase_files()
+        if full and not valid_dataset.with_phase:
+            print("Warning: the validation set has no *_phase.npy files -- its loss is the L1 part only.")
     alpha_mr = ALPHA_MR if full else 0.0
     print(f"Objective: {ALPHA_L1} * L1" + (f" + {ALPHA_MR} * MR-STFT (train.py:296)" if full else " (L1 terms only)"))
 
@@ -318,7 +333,7 @@ def main(argv=None):
                 for mix, voc, mph, vph in valid_loader:
                     mix, voc = mix.to(device), voc.to(device)
                     val_sum += ALPHA_L1 * float(l1_terms(model, mix, voc))
-                    if full:                                               # train.py:341-346
+                    if full and valid_dataset.with_phase:                  # train.py:341-346
                         val_sum += alpha_mr * float(mr_term(model, mix, voc, mph.to(device), vph.to(device)))
             avg_val_loss = val_sum / len(valid_loader)
             log_buffer.append(f"Val {avg_val_loss}\n")

@@ -665,6 +665,54 @@ def test_stft_istft(report):
     assert report("peak normalise", (o2 - out / out.abs().max() * 0.9).abs().max().item(), 1e-6)
 
 
+@pytest.mark.parametrize("hop", [256, 512, 384, 128, 100, 50, 640])
+def test_istft_any_hop(hop, report):
+    """The inverse for hops other than the config's 768 (data.py:24-25 `--hop_size`; config.py:14-25 records runs at
+    HOP_SIZE = 256: four frames per sample): hop < 512 goes through the general overlap-add kernel, hop >= 512 through the
+    two-frames-per-sample one.  Checked against torch.istft in float64 with the arguments of train.py:51-58 / data.py:159
+    (both phase forms, two channels with a mask), the stft -> istft round trip, and the adjoint (`svs_istft_bwd_mask`)
+    against autograd through torch.istft."""
+    from svs_unet_pytorch_amd.data import istft, specific_istft, stft_magphase
+    win = torch.hann_window(1024, dtype=torch.float64)
+    n = 40000 if hop >= 100 else 12000
+    y = synth.audio(n)
+    mag, ph = stft_magphase(torch.from_numpy(y).to(DEV), 1024, hop)
+    T = 1 + n // hop
+    assert mag.shape == (513, T)
+    d = torch.stft(torch.from_numpy(y).double(), 1024, hop, 1024, win, center=True, pad_mode="constant", return_complex=True)
+    assert report(f"stft hop={hop} vs torch.stft", (torch.view_as_complex(torch.view_as_real(ph).cpu().double()) * mag.cpu().double() - d).abs().max().item()
+                  / d.abs().max().item(), 2e-6)
+    got = istft(mag, ph, 1024, hop).cpu().double()
+    want = torch.istft(d, n_fft=1024, hop_length=hop, win_length=1024, window=win, return_complex=False)
+    assert got.shape == want.shape == (hop * (T - 1),)
+    # hops above n_fft / 2 have envelope troughs (0.043 at hop 768) that amplify fp32 noise, and the envelope falls to zero at
+    # both ends of the signal: interior only there; with four or more frames on every sample the whole signal is compared
+    interior = slice(None) if hop <= 256 else slice(1024, -1024)
+    tol = 2e-5 if 1024 % hop == 0 else 1e-4
+    assert report(f"istft hop={hop} phasor form vs torch.istft (interior)", (got - want).abs()[interior].max().item() / want.abs().max().item(), tol)
+    assert report(f"stft->istft round trip hop={hop}", (got[interior] - torch.from_numpy(y).double()[:hop * (T - 1)][interior]).abs().max().item(), 5 * tol)
+    # angle form, batch of 3 training-shaped tiles (DC row dropped), T = 40 frames
+    B, Tt = 3, 40
+    m = synth.uniform(3, B * 512 * Tt).reshape(B, 1, 512, Tt)
+    a = (synth.uniform(4, B * 512 * Tt) * 2 * np.pi - np.pi).astype(np.float32).reshape(B, 1, 512, Tt)
+    got = specific_istft(torch.from_numpy(m).to(DEV), torch.from_numpy(a).to(DEV), 1024, hop).cpu().double()
+    m64 = torch.nn.functional.pad(torch.from_numpy(m).double(), (0, 0, 1, 0)).requires_grad_(True)
+    a64 = torch.nn.functional.pad(torch.from_numpy(a).double(), (0, 0, 1, 0))
+    want = torch.istft(torch.polar(m64, a64).squeeze(1), n_fft=1024, hop_length=hop, win_length=1024, window=win, return_complex=False)
+    assert got.shape == (B, 1, hop * (Tt - 1))
+    e = (got[:, 0] - want.detach()).abs()[:, interior].max().item() / want.abs().max().item()
+    assert report(f"specific_istft hop={hop} vs torch.istft (interior)", e, tol)
+    # adjoint: d sum(w * wav) / d mag through torch.istft, against svs_istft_bwd_mask with mix = 1, mask = 1/2 (factor 1/4)
+    wgt = torch.from_numpy(synth.uniform(8, B * hop * (Tt - 1)).reshape(B, hop * (Tt - 1))).double() - 0.5
+    (want * wgt).sum().backward()
+    dmag = m64.grad[:, :, 1:, :]
+    ones, half = torch.ones((B, 1, 512, Tt), device=DEV), torch.full((B, 1, 512, Tt), 0.5, device=DEV)
+    d_logit = torch.zeros((B, 1, 512, Tt), device=DEV)
+    _lib.check(L().svs_istft_bwd_mask(wgt.float().to(DEV).data_ptr(), torch.from_numpy(a).to(DEV).data_ptr(), ones.data_ptr(), half.data_ptr(),
+                                      d_logit.data_ptr(), 4.0, B, 1024, hop, Tt, S()))
+    assert report(f"istft_bwd_mask hop={hop} vs autograd(torch.istft)", (d_logit.cpu().double() - dmag).abs().max().item() / dmag.abs().max().item(), 5 * tol)
+
+
 def test_specific_istft_golden(golden, report):
     """svs_istft (angle form) through data.specific_istft against the output of the reference's own specific_istft
     (train.py:33-60, captured by oracle/gen_golden_train.py from the reference function object)."""

@@ -110,8 +110,8 @@ def test_signal_path_edge_cases(report):
         _lib.check(L().svs_stft_fwd(y.data_ptr(), 0, 1024, 768, mag.data_ptr(), None, S()))
     tiles, phase, _, T = stft_to_tiles(y)
     out = torch.empty(4096, device=DEV)
-    with pytest.raises(RuntimeError, match="hop"):                              # a sample covered by more than two frames: not built
-        _lib.check(L().svs_istft_tiles(tiles.data_ptr(), 512 * 128, 128, 512, 1, None, 0, torch.view_as_real(phase).data_ptr(), 1, 1, 1024, 256, T,
+    with pytest.raises(RuntimeError, match="hop"):                              # hop > n_fft would leave samples that no frame covers
+        _lib.check(L().svs_istft_tiles(tiles.data_ptr(), 512 * 128, 128, 512, 1, None, 0, torch.view_as_real(phase).data_ptr(), 1, 1, 1024, 1025, T,
                                        out.data_ptr(), None, S()))
     # all-zero input: magnitudes 0, phasors (1, 0) like numpy's angle(0) = 0 (data.py:81 librosa.magphase), inverse 0
     tiles, phase, peak, T = stft_to_tiles(y)

@@ -412,56 +412,62 @@ def test_eval_forward_is_graph_capturable(report):
     assert torch.equal(static_out, want2) and not torch.equal(want, want2)
 
 
-def test_train_step_b64_golden(golden, report):
-    """BASELINE configs[2] at its own size: one L1 train step at B = 64 through the DEFAULT planner (the tile shapes,
-    K-splits, window kernels and two-stream schedule that bench.py times) against the reference's own model run at B = 64
-    in float64 / float32 (oracle/gen_golden_train.py): loss, all 46 gradient norms, a 64-element sample of every gradient
-    tensor, BatchNorm running statistics and the parameters after the Adam step."""
-    g = golden("train_b64.npz")
+@pytest.mark.parametrize("B,split", [(64, 0), (64, 1), (128, 0), (256, 0), (512, 0), (512, 1)])
+def test_train_step_b64_golden(golden, report, tune, B, split):
+    """BASELINE configs[2] at its own size, and the single-GPU legs of configs[3] (global batch 512 on 4 / 2 / 1 GPUs =
+    B 128 / 256 / 512 per GPU: what bench.py's `strong_b512` record and the strong-scaling runs execute): one L1 train step
+    through the DEFAULT planner (the tile shapes, K-splits, window kernels, workspace layout and two-stream schedule that
+    bench.py times) against the reference's own model run at that batch size in float64 / float32
+    (oracle/gen_golden_train.py): loss, all 46 gradient norms, a 64-element sample of every gradient tensor, BatchNorm
+    running statistics and the parameters after the Adam step.  split = 1: the optional split-bf16 product mode
+    (csrc/mfma_split.h), same tolerances."""
+    g = golden(f"train_b{B}.npz")
     names = list(g["param_names"])
-    B = 64
+    if split:
+        tune("MFMA_SPLIT", 1)
     mix_np, voc_np = synth.tiles(B)
     mix, voc = torch.from_numpy(mix_np).to(DEV), torch.from_numpy(voc_np).to(DEV)
+    del mix_np, voc_np
     model = make_model(trained_stats=False).train()
     assert [n for n, _ in model.named_parameters()] == names
-    model.set_dropout_masks([torch.from_numpy(m) for m in synth.dropout_masks(B, seed=64, step=0)])
+    model.set_dropout_masks([torch.from_numpy(m) for m in synth.dropout_masks(B, seed=int(g["mask_seed"]) if "mask_seed" in g.files else 64, step=0)])
     model.optim.zero_grad()
     loss = model.fwd_bwd(mix, voc)
     want = float(g["f64.loss"])
-    assert report("train B=64 loss vs reference fp64 (gate 1e-5)", abs(loss.item() - want) / want, 1e-5)
+    assert report(f"train B={B} loss vs reference fp64 (gate 1e-5)", abs(loss.item() - want) / want, 1e-5)
     grads = _grads_by_name(model)
     gn64, gn32 = g["f64.grad_norm"], g["f32.grad_norm"]
     total64 = float(np.sqrt((gn64 ** 2).sum()))
     total = float(np.sqrt(sum(grads[n].norm().item() ** 2 for n in names)))
-    assert report("train B=64 global gradient norm (gate 1e-4)", abs(total - total64) / total64, 1e-4)
+    assert report(f"train B={B} global gradient norm (gate 1e-4)", abs(total - total64) / total64, 1e-4)
     for i, n in enumerate(names):
         got = grads[n].norm().item()
         noise = max(abs(gn32[i] - gn64[i]), 1e-4 * gn64[i], 2e-6)
-        assert report(f"train B=64 |grad| {n}", abs(got - gn64[i]) / noise, 20.0), (n, got, gn64[i], gn32[i])
+        assert report(f"train B={B} |grad| {n}", abs(got - gn64[i]) / noise, 20.0), (n, got, gn64[i], gn32[i])
         if gn64[i] > 1e-6:
             # SURVEY 8(d) gate 1e-4 per tensor, or 3x the reference's own fp32 deviation, with an absolute floor of 1e-6 of
             # the global gradient norm for the near-zero tensors (BatchNorm shifts deep in the encoder: |g| ~ 1e-4)
             gate = max(1e-4, 3 * abs(gn32[i] - gn64[i]) / gn64[i], 1e-6 * total64 / gn64[i])
-            assert report(f"train B=64 |grad| rel {n} (gate 1e-4)", abs(got - gn64[i]) / gn64[i], gate)
+            assert report(f"train B={B} |grad| rel {n} (gate 1e-4)", abs(got - gn64[i]) / gn64[i], gate)
         f = grads[n].reshape(-1)
         stp = max(f.numel() // 64, 1)
         w64, w32 = g["f64.grad_sample." + n].astype(np.float64), g["f32.grad_sample." + n].astype(np.float64)
         noise = max(np.abs(w32 - w64).max(), 1e-4 * np.abs(w64).max(), 1e-9)
-        assert report(f"train B=64 grad sample {n}", np.abs(f[::stp][:64].numpy() - w64).max() / noise, 20.0)
+        assert report(f"train B={B} grad sample {n}", np.abs(f[::stp][:64].numpy() - w64).max() / noise, 20.0)
     model.optim.step()
     sd = model.state_dict()
     for k in sd:
         if "running_" in k:
             want_b = g["f64.buf." + k]
-            assert report(f"train B=64 {k}", np.abs(sd[k].cpu().numpy() - want_b).max() / max(np.abs(want_b).max(), 1e-3), 1e-5)
+            assert report(f"train B={B} {k}", np.abs(sd[k].cpu().numpy() - want_b).max() / max(np.abs(want_b).max(), 1e-3), 1e-5)
     for n in ("conv1.0.weight", "conv6.0.weight", "deconv1.weight", "deconv6.weight"):
         f = sd[n].reshape(-1).cpu()
         stp = max(f.numel() // 64, 1)
         # Adam's first step moves every weight by lr * sign(g): only the sign of the gradient matters, and elements whose
         # gradient is at the rounding-noise level may flip -- allow 2*lr on those, require most to agree to 1e-6
         d = np.abs(f[::stp][:64].numpy() - g["f64.param_after." + n])
-        assert report(f"train B=64 params after Adam {n} (max)", d.max(), 2.1e-3)
-        assert report(f"train B=64 params after Adam {n} (share off)", float((d > 1e-6).mean()), 0.1)
+        assert report(f"train B={B} params after Adam {n} (max)", d.max(), 2.1e-3)
+        assert report(f"train B={B} params after Adam {n} (share off)", float((d > 1e-6).mean()), 0.1)
 
 
 def test_eval_cache_follows_every_kind_of_weight_change(report):

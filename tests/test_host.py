@@ -267,3 +267,37 @@ def test_library_has_no_packed_fp32_op_sel_forms():
     hits, n_inst, n_kernels = mod.scan(lib)
     assert n_kernels > 100 and n_inst > 100000                 # the scan really saw the device code
     assert not hits, hits[:5]
+
+
+def test_bench_gpus_n_launches_child_ranks(tmp_path):
+    """`python bench.py --gpus N` with no launcher around it starts N child ranks itself (before any GPU call), forwards rank 0's
+    one JSON line and fails when a rank fails.  The ranks here are a stub script (SVS_BENCH_WORKER) that checks the rendezvous
+    environment the real worker reads; on this GPU-less box the real worker must fail with a clear message."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    stub = tmp_path / "stub_rank.py"
+    stub.write_text(
+        "import json, os, sys\n"
+        "r, w = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])\n"
+        "assert int(os.environ['LOCAL_RANK']) == r and os.environ['MASTER_ADDR'] == '127.0.0.1' and int(os.environ['MASTER_PORT']) > 0\n"
+        "assert sys.argv[1:] == ['--gpus', str(w), '--steps', '2'], sys.argv\n"
+        "if os.environ.get('STUB_FAIL_RANK') == str(r):\n"
+        "    sys.exit(3)\n"
+        "print('chatter from rank', r)\n"
+        "if r == 0:\n"
+        "    print(json.dumps({'metric': 'stub', 'n_gpus': w, 'port': int(os.environ['MASTER_PORT'])}))\n")
+    env = dict(os.environ, SVS_BENCH_WORKER=str(stub))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--steps", "2"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 3, r.stdout
+    assert "chatter from rank 0" in r.stderr and "chatter from rank 2" in r.stderr
+    r = subprocess.run(cmd, env=dict(env, STUB_FAIL_RANK="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 3 and not r.stdout.strip() and "rank 1 exited with code 3" in r.stderr, (r.returncode, r.stdout, r.stderr[-500:])
+    if not torch.cuda.is_available():
+        env.pop("SVS_BENCH_WORKER")
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and not r.stdout.strip() and "sees no GPU" in r.stderr, (r.returncode, r.stderr[-500:])

@@ -243,7 +243,7 @@ def test_mrstft_oracle_against_direct_numpy_frames():
             spec = np.fft.rfft(fr, axis=-1)
             mags.append(np.sqrt(np.maximum(spec.real ** 2 + spec.imag ** 2, mo.EPS)))
         xm, ym = mags
-        sc = np.sqrt(((ym - xm) ** 2).sum()) / np.sqrt((ym ** 2).sum())
+        sc = (np.sqrt(((ym - xm) ** 2).sum(axis=(1, 2))) / np.sqrt((ym ** 2).sum(axis=(1, 2)))).mean()     # per waveform, then the mean
         total += sc + np.abs(np.log(xm) - np.log(ym)).mean()
     want = total / 3
     got = float(mo.mrstft_loss(torch.from_numpy(x), torch.from_numpy(y)))
