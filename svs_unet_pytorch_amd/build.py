@@ -41,7 +41,7 @@ def _stale(target, deps):
 # vectoriser turns complex multiplies into v_pk_mul_f32 / v_pk_fma_f32 with op_sel swizzles, and on gfx950 a packed-fp32
 # instruction whose op_sel takes the HIGH half of a source for the low result returns garbage while a bf16 MFMA
 # (v_mfma_f32_16x16x32_bf16) of any other wave -- another stream, another process -- is executing on the CU
-# (tools/stress_victims.py reproduces it with two-line kernels).  No other source file produces that form.
+# (tools/attic/stress_victims.py reproduces it with two-line kernels).  No other source file produces that form.
 EXTRA_FLAGS = {"stft.hip": ["-fno-slp-vectorize"], "mrstft.hip": ["-fno-slp-vectorize"]}
 
 

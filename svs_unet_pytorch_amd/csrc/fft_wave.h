@@ -156,7 +156,7 @@ struct FftPass {
 // NOTE for every file that includes this header: build it with -fno-slp-vectorize (svs_unet_pytorch_amd/build.py).  The SLP
 // vectoriser turns complex multiplies into packed-fp32 instructions with op_sel swizzles, and on gfx950 a v_pk_{add,mul,fma}_f32
 // whose op_sel takes the HIGH half of a source for the low result returns garbage while a bf16 MFMA of any other wave is
-// executing on the CU (whole frames of garbage as soon as another stream or process ran the bf16 network; tools/stress_victims.py,
+// executing on the CU (whole frames of garbage as soon as another stream or process ran the bf16 network; tools/attic/stress_victims.py,
 // tools/check_isa.py).  Without the packed forms the transforms are also 5-10 % faster.
 __device__ __forceinline__ void fft_wave_sync() { __builtin_amdgcn_wave_barrier(); }
 template <int N>

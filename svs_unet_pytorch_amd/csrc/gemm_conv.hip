@@ -45,6 +45,24 @@ struct ConvGemmArgs {
                                   // for the GEMM, = block for the window kernel); null = off
 };
 
+// Balanced K-splits of the tap-skipping kernels (SKIP = true, batch a multiple of the tile height: an M-tile is then ONE pixel
+// position of BM images).  On the deep levels a position has 9 .. 25 taps inside the image, so with one K-split count for the
+// whole layer the blocks of a launch differ in length by up to 2.8x (and a split whose K range lies in the padding does
+// nothing); all blocks of these launches are resident at once, so the launch lasts as long as the most loaded CU: 1.2-1.5x
+// the mean (rocprofv3: MFMA-busy 0.39-0.46 of these launches against 0.65-0.72 of the ones with even blocks).  Here every
+// position gets its OWN number of splits, proportional to its valid K-tiles, each split an equal share of the VALID K-tiles
+// only; the host lays the blocks out as (class, position, M-tile, split, N-tile) in one 1-D grid and picks the split size that
+// minimises the modelled load of the most loaded CU.  Block -> position by a 64-lane ballot over `first`.  Slab z of a row
+// exists only for z < its position's split count, which the blocks record per output row (`rowsplit`) for the epilogue.
+struct ConvBal {
+  int enabled;                    // 0: uniform grid (tiles, K-splits, classes)
+  int npos[4];                    // positions (= Ha * Wa) of each parity class (GATHER: class 0 only)
+  unsigned first[4][65];          // first[c][pos]: first block of position pos of class c; first[c][npos[c]] = one past its last
+  unsigned char nsplit[4][64];
+  unsigned char* rowsplit;        // [B * Ho * Wo] (workspace, behind the slabs)
+};
+struct ConvNoBal {};
+
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 3); }
 
 // SKIP = true: rows are ordered (w, h, b) -- batch innermost -- instead of (b, h, w).  On the deep levels the images
@@ -54,7 +72,7 @@ __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >>
 // -15% on 16x4.  Skipped products are exact zeros, so results do not change.  Needs tap-outer K order and C/16 a
 // power of two.
 template <int MODE, int BM, int BN, int WM, int WN, bool SKIP = false, bool SPLIT = false>     // SPLIT: mfma_split.h (optional mode)
-__global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs p) {
+__global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs p, std::conditional_t<SKIP, ConvBal, ConvNoBal> bal) {
   constexpr int TM = BM / WM / 16;
   constexpr int TN = BN / WN / 16;
   constexpr int RA = (BM + 63) / 64;   // A rows staged per thread
@@ -71,11 +89,31 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs p) {
   const int lrow = lane & 15, q = lane >> 4;
 
   // ---- geometry of this block ---------------------------------------------------------------
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;     // (tile, K-split, parity class)
+  int nsplit = p.ksplit;                                     // K-splits of this block's M-tile
+  bool balanced = false;
+  if constexpr (SKIP) {
+    if (bal.enabled) {                                       // 1-D grid: (class, position, M-tile of the position, split, N-tile)
+      balanced = true;
+      const unsigned bid = blockIdx.x;
+      int c = 0;
+      if (MODE == MODE_PARITY) c = (bid >= bal.first[1][0]) + (bid >= bal.first[2][0]) + (bid >= bal.first[3][0]);
+      const unsigned f = lane < bal.npos[c] ? bal.first[c][lane] : 0xFFFFFFFFu;
+      const int pos = __builtin_amdgcn_readfirstlane(__builtin_popcountll(__ballot(f <= bid)) - 1);
+      nsplit = bal.nsplit[c][pos];
+      const int ntn = p.N / BN, per = nsplit * ntn;
+      const int within = (int)(bid - bal.first[c][pos]);
+      const int i = within / per, rem = within - i * per;
+      by = rem / ntn;
+      bx = (pos * (p.B / BM) + i) * ntn + (rem - by * ntn);
+      bz = c;
+    }
+  }
   int ph = 0, pw = 0, nth = 5, ntw = 5;
   int Ha, Wa;                      // rows / cols of the M grid
   const float* wp = p.wp;
   if (MODE == MODE_PARITY) {
-    const int par = blockIdx.z;             // classes outermost in dispatch order: all the long (9-tap) blocks start first
+    const int par = bz;                     // classes outermost in dispatch order: all the long (9-tap) blocks start first
     ph = par >> 1; pw = par & 1;
     nth = 3 - ph; ntw = 3 - pw;
     Ha = (p.Ho - ph + 1) >> 1; Wa = (p.Wo - pw + 1) >> 1;
@@ -87,19 +125,19 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs p) {
   const int ntaps = nth * ntw;
   const long M = (long)p.B * Ha * Wa;
   const int ntile_n = p.N / BN;
-  const long m0 = (long)(blockIdx.x / ntile_n) * BM;
-  const int n0 = (blockIdx.x % ntile_n) * BN;
+  const long m0 = (long)(bx / ntile_n) * BM;
+  const int n0 = (bx % ntile_n) * BN;
   if (m0 >= M) {                   // parity classes of odd-sized outputs are smaller
     if (p.stats && p.ksplit == 1) {                // their statistics row must still exist
-      float* out = p.stats + ((long)blockIdx.z * (gridDim.x / ntile_n) + blockIdx.x / ntile_n) * 2 * p.N + n0;
+      float* out = p.stats + ((long)bz * (gridDim.x / ntile_n) + bx / ntile_n) * 2 * p.N + n0;
       for (int c = threadIdx.x; c < BN; c += 256) { out[c] = 0.f; out[p.N + c] = 0.f; }
     }
     return;
   }
   const int cpt = p.C >> 4;        // K-tiles per tap
   const int nkt = ntaps * cpt;
-  const int kt_begin = (int)((long)nkt * blockIdx.y / p.ksplit);
-  const int kt_end = (int)((long)nkt * (blockIdx.y + 1) / p.ksplit);
+  int kt_begin = (int)((long)nkt * by / nsplit);
+  int kt_end = (int)((long)nkt * (by + 1) / nsplit);
   const long Kw = (long)ntaps * p.C;   // weight row length
 
   // ---- per-thread staging rows -----------------------------------------------------------------
@@ -154,6 +192,17 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs p) {
     if (mine) atomicOr(&umask_s, mine);
     __syncthreads();
     umask = __builtin_amdgcn_readfirstlane(umask_s);
+    if (balanced) {                // this split's equal share of the VALID K-tiles: ranks [vb, ve) among the set taps of umask
+      const int nvk = __builtin_popcount(umask) << p.cpt_shift;
+      const int vb = (int)((long)nvk * by / nsplit), ve = (int)((long)nvk * (by + 1) / nsplit);
+      auto kt_of = [&](int v) -> int {               // v-th valid K-tile -> K-tile index (scalar loop over <= 25 bits)
+        unsigned m = umask;
+        for (int r = v >> p.cpt_shift; r > 0; --r) m &= m - 1;
+        return (__builtin_ctz(m) << p.cpt_shift) | (v & (cpt - 1));
+      };
+      kt_begin = vb < nvk ? kt_of(vb) : nkt;
+      kt_end = ve < nvk ? kt_of(ve) : nkt;
+    }
   }
   unsigned b_voff[RB];
 #pragma unroll
@@ -271,7 +320,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs p) {
   float ssum[TN], ssq[TN];               // per-lane column sums of the values written (BatchNorm statistics)
 #pragma unroll
   for (int j = 0; j < TN; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
-  float* const slab = split ? p.slab + (long)blockIdx.y * ((long)p.B * p.Ho * p.Wo) * p.N : nullptr;
+  float* const slab = split ? p.slab + (long)by * ((long)p.B * p.Ho * p.Wo) * p.N : nullptr;
+  bool mark_rows = false;                // balanced: split 0 of N-tile 0 records how many slabs its rows have
+  if constexpr (SKIP) mark_rows = balanced && by == 0 && n0 == 0 && wn == 0;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -295,6 +346,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs p) {
         const long b = ub;
         opix = (b * p.Ho + 2 * hq + ph) * p.Wo + 2 * wq + pw;
       }
+      if constexpr (SKIP) { if (mark_rows && lrow == 0) bal.rowsplit[opix] = (unsigned char)nsplit; }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * (TN * 16) + j * 16 + lrow;
@@ -326,7 +378,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs p) {
       if (q == 0) { st[0][wm][wn * (TN * 16) + j * 16 + lrow] = ssum[j]; st[1][wm][wn * (TN * 16) + j * 16 + lrow] = ssq[j]; }
     }
     __syncthreads();
-    float* out = p.stats + ((long)blockIdx.z * (gridDim.x / ntile_n) + blockIdx.x / ntile_n) * 2 * p.N + n0;
+    float* out = p.stats + ((long)bz * (gridDim.x / ntile_n) + bx / ntile_n) * 2 * p.N + n0;
     for (int c = t; c < BN; c += 256) {
       float a = 0.f, b2 = 0.f;
 #pragma unroll
@@ -695,7 +747,8 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
                                                               const float* __restrict__ scale,
                                                               const float* __restrict__ shift, float slope,
                                                               float* y, long ldy, int accumulate, float* __restrict__ stats,
-                                                              int n_shift) {      // log2(N) when N is a power of two (every layer here), else -1
+                                                              int n_shift,        // log2(N) when N is a power of two (every layer here), else -1
+                                                              const unsigned char* __restrict__ rowsplit) {   // balanced splits: slabs per row, else null
   __shared__ f32x4 red[2][256];
   const long total4 = P * N / 4;
   const long stride = P * N;
@@ -705,8 +758,9 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
     const long pix = n_shift >= 0 ? (e >> n_shift) : e / N;         // (a 64-bit division per float4 otherwise)
     const int n = (int)(e - pix * N);
     f32x4 s = *(const f32x4*)(slab + e);
+    const int nz = rowsplit ? (int)rowsplit[pix] : ksplit;                              // (ConvBal: a row has as many slabs as its position has splits)
 #pragma unroll 4
-    for (int z = 1; z < ksplit; ++z) s += *(const f32x4*)(slab + z * stride + e);     // (unrolled: four slabs' loads in flight, same order)
+    for (int z = 1; z < nz; ++z) s += *(const f32x4*)(slab + z * stride + e);         // (unrolled: four slabs' loads in flight, same order)
     float* dst = y + pix * ldy + n;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -798,35 +852,127 @@ static ConvPlan plan_conv(int mode, long Mmax, int N, int nkt_min, bool narrow =
 }
 
 template <int MODE, bool SPLIT>
-static void launch_conv_gemm_cfg(const ConvGemmArgs& a, const ConvPlan& pl, dim3 grid, hipStream_t stream, bool skip) {
+static void launch_conv_gemm_cfg(const ConvGemmArgs& a, const ConvPlan& pl, dim3 grid, hipStream_t stream, bool skip, const ConvBal& bal) {
   dim3 block(256);
   if (skip) {                                // batch-innermost rows + padding-tap skipping (deep levels)
     switch (pl.cfg) {
-      case 0: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 128, 128, 2, 2, true, SPLIT>), grid, block, 0, stream, a); break;
-      case 1: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 128, 64, 2, 2, true, SPLIT>), grid, block, 0, stream, a); break;
-      case 4: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 32, 128, 1, 4, true, SPLIT>), grid, block, 0, stream, a); break;
-      case 6: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 64, 128, 2, 2, true, SPLIT>), grid, block, 0, stream, a); break;
-      default: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 64, 64, 2, 2, true, SPLIT>), grid, block, 0, stream, a); break;
+      case 0: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 128, 128, 2, 2, true, SPLIT>), grid, block, 0, stream, a, bal); break;
+      case 1: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 128, 64, 2, 2, true, SPLIT>), grid, block, 0, stream, a, bal); break;
+      case 4: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 32, 128, 1, 4, true, SPLIT>), grid, block, 0, stream, a, bal); break;
+      case 6: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 64, 128, 2, 2, true, SPLIT>), grid, block, 0, stream, a, bal); break;
+      default: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 64, 64, 2, 2, true, SPLIT>), grid, block, 0, stream, a, bal); break;
     }
     return;
   }
+  const ConvNoBal nb{};
   switch (pl.cfg) {
-    case 0: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 128, 128, 2, 2, false, SPLIT>), grid, block, 0, stream, a); break;
-    case 1: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 128, 64, 2, 2, false, SPLIT>), grid, block, 0, stream, a); break;
-    case 2: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 256, 32, 4, 1, false, SPLIT>), grid, block, 0, stream, a); break;
-    case 3: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 256, 16, 4, 1, false, SPLIT>), grid, block, 0, stream, a); break;
-    case 4: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 32, 128, 1, 4, false, SPLIT>), grid, block, 0, stream, a); break;
-    case 6: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 64, 128, 2, 2, false, SPLIT>), grid, block, 0, stream, a); break;
-    default: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 64, 64, 2, 2, false, SPLIT>), grid, block, 0, stream, a); break;
+    case 0: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 128, 128, 2, 2, false, SPLIT>), grid, block, 0, stream, a, nb); break;
+    case 1: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 128, 64, 2, 2, false, SPLIT>), grid, block, 0, stream, a, nb); break;
+    case 2: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 256, 32, 4, 1, false, SPLIT>), grid, block, 0, stream, a, nb); break;
+    case 3: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 256, 16, 4, 1, false, SPLIT>), grid, block, 0, stream, a, nb); break;
+    case 4: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 32, 128, 1, 4, false, SPLIT>), grid, block, 0, stream, a, nb); break;
+    case 6: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 64, 128, 2, 2, false, SPLIT>), grid, block, 0, stream, a, nb); break;
+    default: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 64, 64, 2, 2, false, SPLIT>), grid, block, 0, stream, a, nb); break;
   }
 }
 template <int MODE>
-static int launch_conv_gemm(const ConvGemmArgs& a, const ConvPlan& pl, hipStream_t stream, bool skip) {
+static int launch_conv_gemm(const ConvGemmArgs& a, const ConvPlan& pl, hipStream_t stream, bool skip, const ConvBal& bal) {
   dim3 grid((unsigned)(pl.mtiles * (a.N / pl.BN)), (unsigned)pl.ksplit, (unsigned)pl.grid_y);      // (tiles, K-splits, parity classes)
-  if (svs_tune(SVS_TUNE_MFMA_SPLIT) > 0) launch_conv_gemm_cfg<MODE, true>(a, pl, grid, stream, skip);     // optional mode: mfma_split.h
-  else launch_conv_gemm_cfg<MODE, false>(a, pl, grid, stream, skip);
+  if (skip && bal.enabled) grid = dim3(bal.first[pl.grid_y - 1][bal.npos[pl.grid_y - 1]], 1, 1);     // (class, position, M-tile, split, N-tile)
+  if (svs_tune(SVS_TUNE_MFMA_SPLIT) > 0) launch_conv_gemm_cfg<MODE, true>(a, pl, grid, stream, skip, bal);     // optional mode: mfma_split.h
+  else launch_conv_gemm_cfg<MODE, false>(a, pl, grid, stream, skip, bal);
   SVS_CHECK_LAUNCH("conv_gemm");
   return SVS_OK;
+}
+
+// Host side of ConvBal (see the struct): per-position split counts for a tap-skipping launch.  Returns the number of slabs
+// (the largest split count), 0 = not applicable / not worth it -> uniform grid.  Purely a function of the shape, so the
+// workspace query and the launch agree.
+static int plan_balance(int mode, int B, int H, int W, int C, int Ho, int Wo, int N, const ConvPlan& pl, ConvBal* out) {
+  if (out) out->enabled = 0;
+  if (svs_tune(SVS_TUNE_CONV_BALANCE) == 0 || pl.ksplit <= 1 || B % pl.BM != 0 || (C & (C - 1)) != 0) return 0;
+  const int ncls = (mode == MODE_PARITY) ? 4 : 1, cpt = C / 16, r = B / pl.BM, ntn = N / pl.BN;
+  int npos[4] = {0, 0, 0, 0}, nvk[4][64];
+  long total = 0;
+  for (int c = 0; c < ncls; ++c) {
+    const int ph = c >> 1, pw = c & 1;
+    const int Ha = (mode == MODE_PARITY) ? (Ho - ph + 1) / 2 : Ho, Wa = (mode == MODE_PARITY) ? (Wo - pw + 1) / 2 : Wo;
+    const int nth = (mode == MODE_PARITY) ? 3 - ph : 5, ntw = (mode == MODE_PARITY) ? 3 - pw : 5;
+    if (Ha * Wa > 64 || Ha * Wa < 1) return 0;
+    npos[c] = Ha * Wa;
+    for (int pos = 0; pos < npos[c]; ++pos) {                     // rows are ordered (w, h, b): pos = wq * Ha + hq
+      const int wq = pos / Ha, hq = pos - wq * Ha;
+      int vh = 0, vw = 0;
+      for (int th = 0; th < nth; ++th) { const int ih = (mode == MODE_GATHER) ? 2 * hq - 2 + th : hq + 1 - th; vh += (ih >= 0 && ih < H); }
+      for (int tw = 0; tw < ntw; ++tw) { const int iw = (mode == MODE_GATHER) ? 2 * wq - 2 + tw : wq + 1 - tw; vw += (iw >= 0 && iw < W); }
+      nvk[c][pos] = vh * vw * cpt;
+      total += (long)nvk[c][pos] * r * ntn;
+    }
+  }
+  // candidates: target work per block T (in K-tiles) and a cap on the splits; cost = load of the most loaded CU when the
+  // blocks go to the 256 CUs round-robin in launch order (how the dispatcher is observed to place a grid that is resident at
+  // once; only speed depends on it), each block paying a fixed prologue / epilogue share, plus the epilogue's slab traffic
+  const int NCU = 256;
+  // (units: one K-tile of one block = 4 * TM * TN MFMAs per wave; a 64x64 tile's is 512 cycles.  Fixed cost per block ~ 3 such;
+  //  a slab tile's write + read in the epilogue ~ 0.03 of them chip-wide, whatever the tile: bytes and unit both scale with it)
+  const double OVH = 3.0 * 4096.0 / (pl.BM * pl.BN), SLAB = 0.03;
+  const int smax_hi = pl.ksplit * 2 < 16 ? pl.ksplit * 2 : 16;
+  double best = 1e30;
+  int best_cap = 0; double best_T = 0, best_load = 0;
+  static thread_local double load[256];
+  const long force_nb = svs_tune(SVS_TUNE_CONV_BALANCE) >= 16 ? svs_tune(SVS_TUNE_CONV_BALANCE) : 0;     // sweeps: aim at this many blocks
+  const int caps[2] = {force_nb ? 16 : pl.ksplit, force_nb ? 16 : smax_hi};
+  for (int ci = 0; ci < 2; ++ci) {
+    const int cap = caps[ci];
+    if (ci == 1 && cap == caps[0]) break;
+    // (block counts around the uniform plan's: that count -- 3 to 4 resident blocks per CU -- came out of the tile / split sweeps,
+    //  and the model knows nothing about latency hiding)
+    const long nb_uniform = pl.mtiles * ntn * pl.grid_y * pl.ksplit;
+    for (long nb = force_nb ? force_nb : nb_uniform * 7 / 8; nb <= (force_nb ? force_nb : nb_uniform * 11 / 8); nb += 4) {
+      const double T = (double)total / nb;
+      for (int i = 0; i < NCU; ++i) load[i] = 0.0;
+      long idx = 0, slabs = 0;
+      for (int c = 0; c < ncls; ++c)
+        for (int pos = 0; pos < npos[c]; ++pos) {
+          int sp = (int)(nvk[c][pos] / T + 0.5);
+          sp = sp < 1 ? 1 : sp > cap ? cap : sp;
+          if (sp > nvk[c][pos]) sp = nvk[c][pos];
+          slabs += (long)sp * r * ntn;
+          for (int i = 0; i < r; ++i)
+            for (int j = 0; j < sp; ++j) {
+              const double w = (double)((long)nvk[c][pos] * (j + 1) / sp - (long)nvk[c][pos] * j / sp) + OVH;
+              for (int n = 0; n < ntn; ++n) load[idx++ % NCU] += w;
+            }
+        }
+      double mx = 0.0;
+      for (int i = 0; i < NCU; ++i) mx = load[i] > mx ? load[i] : mx;
+      const double cost = mx + SLAB * (double)slabs;
+      if (cost < best) { best = cost; best_cap = cap; best_T = T; best_load = mx; }
+    }
+  }
+  if (best_cap == 0) return 0;
+  int S = 1;
+  unsigned at = 0;
+  for (int c = 0; c < 4; ++c) {
+    if (out) out->npos[c] = npos[c];
+    for (int pos = 0; pos < npos[c]; ++pos) {
+      int sp = (int)(nvk[c][pos] / best_T + 0.5);
+      sp = sp < 1 ? 1 : sp > best_cap ? best_cap : sp;
+      if (sp > nvk[c][pos]) sp = nvk[c][pos];
+      S = sp > S ? sp : S;
+      if (out) { out->first[c][pos] = at; out->nsplit[c][pos] = (unsigned char)sp; }
+      at += (unsigned)(sp * r * ntn);
+    }
+    if (out) out->first[c][npos[c]] = at;
+    if (out && c + 1 < 4 && c + 1 >= ncls) { out->first[c + 1][0] = at; }
+  }
+  if (S <= 1) return 0;                       // (a layer that needs no slabs stays on its direct epilogue)
+  if (out) out->enabled = 1;
+  if (out && svs_tune(SVS_TUNE_CONV_BALANCE) == 2)      // sweeps: show the plan
+    fprintf(stderr, "[svs] balanced splits mode %d B %d in %dx%dx%d N %d tile %dx%d: uniform ks %d -> slabs %d, %u blocks (%.2f per CU), "
+            "%.1f K-tiles per block, most loaded CU %.0f (+ slabs: %.0f) vs mean %.0f\n", mode, B, H, W, C, N, pl.BM, pl.BN, pl.ksplit, S, at,
+            at / 256.0, best_T, best_load, best, (double)total / NCU);
+  return S;
 }
 
 static int check_gemm_args(const char* who, const float* x, long ldx, int B, int H, int W, int C, const float* wp,
@@ -915,14 +1061,18 @@ int svs_conv_gemm_run(int mode, const float* x, long ldx, int B, int H, int W, i
   const long P = (long)B * Ho * Wo;
   const int window = use_parity_window(mode, B, H, W, C, N, ldx);
   if (window) pl.ksplit = 1;
+  ConvBal bal{};
+  const int nslab_bal = (!window && use_tap_skip(mode, B, C, Wo, N, pl.cfg)) ? plan_balance(mode, B, H, W, C, Ho, Wo, N, pl, &bal) : 0;
+  if (nslab_bal) pl.ksplit = nslab_bal;          // slabs = the largest split count of any position
   a.ksplit = pl.ksplit;
   if (pl.ksplit > 1) {
-    const size_t need = (size_t)pl.ksplit * P * N * sizeof(float);
+    const size_t need = (size_t)pl.ksplit * P * N * sizeof(float) + (nslab_bal ? svs_align_up((size_t)P, 16) : 0);
     if (!ws || ws_bytes < need || !svs_aligned16(ws)) {
       svs_set_error("%s: workspace too small (%zu < %zu)", who, ws_bytes, need);
       return SVS_ERR_WORKSPACE;
     }
     a.slab = (float*)ws;
+    if (nslab_bal) bal.rowsplit = (unsigned char*)ws + (size_t)pl.ksplit * P * N * sizeof(float);
   }
   // LDS-free kernel for the 16-channel outputs (same-device A/B: 1.2-1.3x there; N = 32 is mixed, so it stays on
   // the LDS kernel except in parity mode with a deep reduction)
@@ -973,7 +1123,7 @@ int svs_conv_gemm_run(int mode, const float* x, long ldx, int B, int H, int W, i
     a.stats = stats;                         // one row of partials per (parity class, M-tile)
     *stats_nblk = (int)(pl.mtiles * pl.grid_y);
   }
-  rc = (mode == MODE_GATHER) ? launch_conv_gemm<MODE_GATHER>(a, pl, stream, skip) : launch_conv_gemm<MODE_PARITY>(a, pl, stream, skip);
+  rc = (mode == MODE_GATHER) ? launch_conv_gemm<MODE_GATHER>(a, pl, stream, skip, bal) : launch_conv_gemm<MODE_PARITY>(a, pl, stream, skip, bal);
   if (rc) return rc;
   if (pl.ksplit > 1 && !svs_tune_flag(SVS_TUNE_SKIP_REDUCE)) {      // (the switch lets bench.py time the GEMM kernel alone)
     const long total4 = P * N / 4;
@@ -986,7 +1136,7 @@ int svs_conv_gemm_run(int mode, const float* x, long ldx, int B, int H, int W, i
     int n_shift = -1;
     if ((N & (N - 1)) == 0) { n_shift = 0; while ((1 << n_shift) < N) ++n_shift; }
     hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(grid), dim3(256), 0, stream, a.slab, pl.ksplit, P, N, bias, scale,
-                       shift, slope, y, ldy, accumulate, fuse ? stats : nullptr, n_shift);
+                       shift, slope, y, ldy, accumulate, fuse ? stats : nullptr, n_shift, bal.enabled ? bal.rowsplit : nullptr);
     SVS_CHECK_LAUNCH("splitk_epilogue");
     if (fuse) *stats_nblk = grid;
   }
@@ -1001,9 +1151,16 @@ size_t svs_conv_gemm_workspace(int mode, int B, int H, int W, int C, int Ho, int
   else { Mmax = (long)B * ((Ho + 1) / 2) * ((Wo + 1) / 2); nkt_min = 4 * (C / 16); }
   const int ks_train = plan_conv(mode, Mmax, N, nkt_min, narrow_level(mode, B, C, Wo, N), false).ksplit;
   const int ks_eval = plan_conv(mode, Mmax, N, nkt_min, narrow_level(mode, B, C, Wo, N), true).ksplit;
-  const int ks = ks_train > ks_eval ? ks_train : ks_eval;          // (one workspace serves either kind of call)
+  int ks = ks_train > ks_eval ? ks_train : ks_eval;               // (one workspace serves either kind of call, balanced or not)
+  size_t extra = 0;
+  for (int inference = 0; inference < 2; ++inference) {            // balanced splits (ConvBal) may need more slabs, and the row table
+    const ConvPlan pl = plan_conv(mode, Mmax, N, nkt_min, narrow_level(mode, B, C, Wo, N), inference != 0);
+    const bool window = use_parity_window(mode, B, H, W, C, N, C) != 0;
+    const int sb = (!window && use_tap_skip(mode, B, C, Wo, N, pl.cfg)) ? plan_balance(mode, B, H, W, C, Ho, Wo, N, pl, nullptr) : 0;
+    if (sb) { ks = sb > ks ? sb : ks; extra = svs_align_up((size_t)B * Ho * Wo, 16); }
+  }
   if (ks <= 1) return 0;
-  return (size_t)ks * B * Ho * Wo * N * sizeof(float);
+  return (size_t)ks * B * Ho * Wo * N * sizeof(float) + extra;
 }
 
 // Name (as rocprofv3 prints it) and K-split of the kernel the planner picks for a conv GEMM -- bench.py groups its
@@ -1026,7 +1183,10 @@ int svs_conv_gemm_describe(int mode, int B, int H, int W, int C, int Ho, int Wo,
   if (direct) { snprintf(buf, n, "conv_direct_kernel<%d, 4, %d>", mode, N / 16); return 1; }
   static const int wm[10] = {2, 2, 4, 4, 1, 2, 2, 4, 4, 4}, wn[10] = {2, 2, 1, 1, 4, 2, 2, 1, 1, 1};     // (6 = 64x128, 2x2 waves)
   const ConvPlan pl = plan_conv(mode, Mmax, N, nkt_min, narrow_level(mode, B, C, Wo, N));
+  const bool skip = use_tap_skip(mode, B, C, Wo, N, pl.cfg) != 0;
   snprintf(buf, n, "conv_gemm_kernel<%d, %d, %d, %d, %d, %s, %s>", mode, pl.BM, pl.BN, wm[pl.cfg], wn[pl.cfg],
-           use_tap_skip(mode, B, C, Wo, N, pl.cfg) ? "true" : "false", svs_tune(SVS_TUNE_MFMA_SPLIT) > 0 ? "true" : "false");
-  return pl.ksplit;
+           skip ? "true" : "false", svs_tune(SVS_TUNE_MFMA_SPLIT) > 0 ? "true" : "false");
+  ConvBal show{};
+  const int sb = skip ? plan_balance(mode, B, H, W, C, Ho, Wo, N, pl, svs_tune(SVS_TUNE_CONV_BALANCE) == 2 ? &show : nullptr) : 0;      // balanced: the largest split count
+  return sb ? sb : pl.ksplit;
 }

@@ -3,14 +3,16 @@
 
 The reference is single-process (it has no distributed code at all), so the semantics are chosen here:
   * gradients: all-reduce (SUM, fp32) of the model's flat 9,823,313-element gradient buffer over RCCL/xGMI
-    (`backend="nccl"` is RCCL on ROCm) in THREE pieces that follow the backward pass (`UNet.fwd_bwd_overlapped`):
-    the decoder blocks (tensors 24..45, 21.8 MB, produced first), the conv6 block (13.1 MB) and conv5..conv1
-    (4.4 MB); each piece is reduced on RCCL's stream while the next one is still being computed, so only the last,
-    smallest piece is exchanged after the backward has ended.  xGMI is point-to-point, so few large messages beat many
-    small buckets; three is what the dependency structure of the backward pass offers.  The 1/world mean is folded
-    into the fused Adam kernel (`FusedAdam.grad_scale`), so there is no extra pass over the gradients;
-  * BatchNorm: per-GPU batch statistics (what DistributedDataParallel over the reference would do);
-    running statistics stay per rank and rank 0's are the ones checkpointed;
+    (`backend="nccl"` is RCCL on ROCm) in FOUR pieces that follow the backward pass (`UNet.fwd_bwd_overlapped`):
+    the decoder blocks (tensors 24..45, 21.8 MB, produced first), the conv6 block (13.1 MB), conv5 + conv4 (4.1 MB)
+    and conv3..conv1 (0.26 MB); each piece is reduced on RCCL's stream while the next one is still being computed,
+    so only the last, latency-sized piece is exchanged after the backward has ended.  xGMI is point-to-point, so few
+    large messages beat many small buckets; four is what the dependency structure of the backward pass offers.  The
+    1/world mean is folded into the fused Adam kernel (`FusedAdam.grad_scale`): no extra pass over the gradients;
+  * BatchNorm: per-GPU batch statistics (what DistributedDataParallel over the reference would do); every rank
+    accumulates its own running statistics during an epoch and `average_bn_buffers` takes their mean over the ranks
+    (one all-reduce of 2,016 floats) before every validation pass / checkpoint, so what is saved does not depend on
+    which rank writes it;
   * Dropout2d: the rank is folded into the mask counter, so shards draw independent masks;
   * parameters: identical on every rank after `broadcast_parameters`, and they stay identical because
     every rank applies the same Adam update to the same summed gradient.

@@ -708,7 +708,8 @@ def test_istft_any_hop(hop, report):
     dmag = m64.grad[:, :, 1:, :]
     ones, half = torch.ones((B, 1, 512, Tt), device=DEV), torch.full((B, 1, 512, Tt), 0.5, device=DEV)
     d_logit = torch.zeros((B, 1, 512, Tt), device=DEV)
-    _lib.check(L().svs_istft_bwd_mask(wgt.float().to(DEV).data_ptr(), torch.from_numpy(a).to(DEV).data_ptr(), ones.data_ptr(), half.data_ptr(),
+    dw_d, a_d = wgt.float().to(DEV), torch.from_numpy(a).to(DEV)       # (named: a temporary's storage would be reused by the next one)
+    _lib.check(L().svs_istft_bwd_mask(dw_d.data_ptr(), a_d.data_ptr(), ones.data_ptr(), half.data_ptr(),
                                       d_logit.data_ptr(), 4.0, B, 1024, hop, Tt, S()))
     assert report(f"istft_bwd_mask hop={hop} vs autograd(torch.istft)", (d_logit.cpu().double() - dmag).abs().max().item() / dmag.abs().max().item(), 5 * tol)
 

@@ -55,7 +55,7 @@ def _worker(rank, world, port, out, full):
     try:
         model = _fresh_model()
         broadcast_parameters(model, 0)
-        sync = GradAllReduce(model, overlap=not os.environ.get("SVS_TEST_NO_OVERLAP"))     # (tools/stress_2rank.py: exchange after the backward)
+        sync = GradAllReduce(model, overlap=not os.environ.get("SVS_TEST_NO_OVERLAP"))     # (tools/attic/stress_2rank.py: exchange after the backward)
         assert model.rank == rank and model.optim.grad_scale == 0.5
         mix, voc = _shard(rank)
         extra = _extras(rank, full)

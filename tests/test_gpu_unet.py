@@ -463,11 +463,18 @@ def test_train_step_b64_golden(golden, report, tune, B, split):
     for n in ("conv1.0.weight", "conv6.0.weight", "deconv1.weight", "deconv6.weight"):
         f = sd[n].reshape(-1).cpu()
         stp = max(f.numel() // 64, 1)
-        # Adam's first step moves every weight by lr * sign(g): only the sign of the gradient matters, and elements whose
-        # gradient is at the rounding-noise level may flip -- allow 2*lr on those, require most to agree to 1e-6
+        # Adam's first step moves a weight by lr * g / (|g| + eps): the sign of the gradient, except for elements whose
+        # gradient is not far above eps = 1e-8 (the deep layers at large batch: median |g| ~ 1e-6), where the step still
+        # depends on the VALUE of g with slope lr * eps / (|g| + eps)^2.  Each sampled element may therefore be off by
+        # 1e-6 plus that slope times the fp32 noise of this tensor's gradient (20x the reference's own fp32-vs-fp64
+        # deviation, the gate of the gradient-sample check above), at most 2 * lr.
         d = np.abs(f[::stp][:64].numpy() - g["f64.param_after." + n])
         assert report(f"train B={B} params after Adam {n} (max)", d.max(), 2.1e-3)
-        assert report(f"train B={B} params after Adam {n} (share off)", float((d > 1e-6).mean()), 0.1)
+        w64, w32 = g["f64.grad_sample." + n].astype(np.float64), g["f32.grad_sample." + n].astype(np.float64)
+        g_noise = 20.0 * max(np.abs(w32 - w64).max(), 1e-4 * np.abs(w64).max(), 1e-9)
+        allowed = 1e-6 + np.minimum(2e-3, 1e-3 * 1e-8 * g_noise / (np.abs(w64) + 1e-8) ** 2)
+        assert report(f"train B={B} params after Adam {n} (worst element / its allowance)", float((d / allowed).max()), 1.0)
+        assert report(f"train B={B} params after Adam {n} (share off by > 1e-6)", float((d > 1e-6).mean()), 0.25)
 
 
 def test_eval_cache_follows_every_kind_of_weight_change(report):

@@ -251,7 +251,7 @@ def test_bss_eval_defining_properties(tmp_path):
 
 def test_library_has_no_packed_fp32_op_sel_forms():
     """gfx950: a packed-fp32 instruction whose op_sel takes the high half of a source for the low result returns garbage
-    while a bf16 MFMA of another wave executes on the CU (tools/stress_victims.py on the GPU).  The
+    while a bf16 MFMA of another wave executes on the CU (tools/attic/stress_victims.py on the GPU).  The
     built library must not contain that form anywhere (stft.hip / mrstft.hip are compiled without SLP vectorisation for
     this reason)."""
     import importlib.util

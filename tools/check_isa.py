@@ -3,7 +3,7 @@
 
 Today one rule: no packed-fp32 instruction (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32) with an `op_sel:[...]` modifier that
 takes the HIGH half of a source for the low result.  On gfx950 such an instruction returns garbage while a bf16 MFMA
-(v_mfma_f32_16x16x32_bf16) of any other wave is executing on the same CU (tools/stress_victims.py); the
+(v_mfma_f32_16x16x32_bf16) of any other wave is executing on the same CU (tools/attic/stress_victims.py); the
 compiler produces the form when it SLP-vectorises complex arithmetic, which is why stft.hip / mrstft.hip are built with
 -fno-slp-vectorize (svs_unet_pytorch_amd/build.py).
 
