@@ -19,8 +19,11 @@
 //
 // Bound: MFMA (fp32 157.3 TFLOP/s peak); algorithmic FLOPs = 2*M*N*K.
 #include <stdlib.h>
+#include <string.h>
 
+#include <mutex>
 #include <type_traits>
+#include <vector>
 #include "common.h"
 #include "mfma_split.h"
 
@@ -816,6 +819,9 @@ static ConvPlan plan_conv(int mode, long Mmax, int N, int nkt_min, bool narrow =
   // beats 128x128 on every such layer, by 20 % on the 8x2 parity layers).
   if (narrow && N % 64 == 0) { pl.cfg = 5; pl.BM = 64; pl.BN = 64; }
   if (narrow && N == 128 && !(v2 && Mmax < (mode == MODE_PARITY ? 2048 : 8192))) { pl.cfg = 6; pl.BM = 64; pl.BN = 128; }     // (batch 64: deconv2 forward -9 %, conv4 fwd / conv5 bwd-data -2 %; batch 16: 64x64 is 10-15 % ahead)
+  // conv5 forward (16x4 anchors, 128 -> 256 channels) with balanced K-splits (ConvBal): the 64x128 tile at 3 blocks per CU is
+  // 13 % ahead of 64x64 in either form (68 vs 78 us at batch 64)
+  if (narrow && mode == MODE_GATHER && N == 256 && nkt_min == 200 && Mmax >= 4096 && Mmax % 64 == 0 && !v2 && svs_tune(SVS_TUNE_CONV_BALANCE) != 0) { pl.cfg = 6; pl.BM = 64; pl.BN = 128; }
   // Optional split-bf16 product mode (mfma_split.h): the MFMA part of a K-tile is 2.7x shorter, the per-fragment limb split is
   // paid once per (row tile + column tile) of a wave, so LARGER wave tiles win (batch-64 sweep in that mode: 128x128 / 64x128
   // ahead of 64x64 by 8-30 % on every N >= 128 layer, 128x64 on the N = 64 ones), at two blocks per CU
@@ -888,7 +894,27 @@ static int launch_conv_gemm(const ConvGemmArgs& a, const ConvPlan& pl, hipStream
 // Host side of ConvBal (see the struct): per-position split counts for a tap-skipping launch.  Returns the number of slabs
 // (the largest split count), 0 = not applicable / not worth it -> uniform grid.  Purely a function of the shape, so the
 // workspace query and the launch agree.
+static int plan_balance_search(int mode, int B, int H, int W, int C, int Ho, int Wo, int N, const ConvPlan& pl, ConvBal* out);
+// memoised: the search walks a few hundred candidate plans of ~1000 blocks each (0.2-0.7 ms of host time -- per LAUNCH it would
+// cost more than the kernel it plans); a handful of distinct shapes per process
 static int plan_balance(int mode, int B, int H, int W, int C, int Ho, int Wo, int N, const ConvPlan& pl, ConvBal* out) {
+  struct Key { int v[12]; bool operator==(const Key& o) const { return !memcmp(v, o.v, sizeof(v)); } };
+  struct Entry { Key k; int slabs; ConvBal bal; };
+  static std::mutex mu;
+  static std::vector<Entry> cache;
+  const Key key{{mode, B, H, W, C, Ho, Wo, N, pl.BM, pl.BN, pl.ksplit, (int)svs_tune(SVS_TUNE_CONV_BALANCE)}};
+  std::lock_guard<std::mutex> lock(mu);
+  for (const Entry& e : cache)
+    if (e.k == key) { if (out) { unsigned char* rs = out->rowsplit; *out = e.bal; out->rowsplit = rs; } return e.slabs; }
+  Entry e{};
+  e.k = key;
+  e.slabs = plan_balance_search(mode, B, H, W, C, Ho, Wo, N, pl, &e.bal);
+  if (cache.size() > 256) cache.clear();
+  cache.push_back(e);
+  if (out) { unsigned char* rs = out->rowsplit; *out = e.bal; out->rowsplit = rs; }
+  return e.slabs;
+}
+static int plan_balance_search(int mode, int B, int H, int W, int C, int Ho, int Wo, int N, const ConvPlan& pl, ConvBal* out) {
   if (out) out->enabled = 0;
   if (svs_tune(SVS_TUNE_CONV_BALANCE) == 0 || pl.ksplit <= 1 || B % pl.BM != 0 || (C & (C - 1)) != 0) return 0;
   const int ncls = (mode == MODE_PARITY) ? 4 : 1, cpt = C / 16, r = B / pl.BM, ntn = N / pl.BN;
@@ -920,7 +946,18 @@ static int plan_balance(int mode, int B, int H, int W, int C, int Ho, int Wo, in
   double best = 1e30;
   int best_cap = 0; double best_T = 0, best_load = 0;
   static thread_local double load[256];
-  const long force_nb = svs_tune(SVS_TUNE_CONV_BALANCE) >= 16 ? svs_tune(SVS_TUNE_CONV_BALANCE) : 0;     // sweeps: aim at this many blocks
+  // Same-device sweep at batch 64 (tools/gemm_sweep.py --ab-env CONV_BALANCE, targets 512 .. 1536): multiples of 256 blocks win
+  // (the round-robin model), 3 per CU for the GATHER direction and 5 per CU for the PARITY one; the 8x2-anchor layers gain
+  // 10-15 % (conv6 / deconv1, both directions), conv5 forward 13 % with the 64x128 tile, the 16x4-anchor PARITY layers LOSE
+  // 5-10 % (their uniform grid is 256 blocks per parity class, which round-robin already spreads evenly): rule below.
+  int max_pos = 0;
+  for (int c = 0; c < ncls; ++c) max_pos = npos[c] > max_pos ? npos[c] : max_pos;
+  const bool tuned = max_pos <= 16 || (mode == MODE_GATHER && max_pos <= 64 && pl.BN == 128);
+  long force_nb = svs_tune(SVS_TUNE_CONV_BALANCE) >= 16 ? svs_tune(SVS_TUNE_CONV_BALANCE) : 0;     // sweeps: aim at this many blocks
+  if (!force_nb && svs_tune(SVS_TUNE_CONV_BALANCE) != 3) {      // (3: the cost-model search below, for comparison)
+    if (!tuned) return 0;
+    force_nb = mode == MODE_GATHER ? 768 : 1280;
+  }
   const int caps[2] = {force_nb ? 16 : pl.ksplit, force_nb ? 16 : smax_hi};
   for (int ci = 0; ci < 2; ++ci) {
     const int cap = caps[ci];
@@ -928,7 +965,10 @@ static int plan_balance(int mode, int B, int H, int W, int C, int Ho, int Wo, in
     // (block counts around the uniform plan's: that count -- 3 to 4 resident blocks per CU -- came out of the tile / split sweeps,
     //  and the model knows nothing about latency hiding)
     const long nb_uniform = pl.mtiles * ntn * pl.grid_y * pl.ksplit;
-    for (long nb = force_nb ? force_nb : nb_uniform * 7 / 8; nb <= (force_nb ? force_nb : nb_uniform * 11 / 8); nb += 4) {
+    // a target count: the largest plan that does NOT exceed it (one block too many puts a whole extra block on some CUs);
+    // no target: every size around the uniform plan's, by the cost model
+    const long nb_lo = force_nb ? force_nb / 2 : nb_uniform * 7 / 8, nb_hi = force_nb ? force_nb : nb_uniform * 11 / 8;
+    for (long nb = nb_hi; nb >= nb_lo; nb -= 4) {
       const double T = (double)total / nb;
       for (int i = 0; i < NCU; ++i) load[i] = 0.0;
       long idx = 0, slabs = 0;
@@ -947,10 +987,28 @@ static int plan_balance(int mode, int B, int H, int W, int C, int Ho, int Wo, in
       double mx = 0.0;
       for (int i = 0; i < NCU; ++i) mx = load[i] > mx ? load[i] : mx;
       const double cost = mx + SLAB * (double)slabs;
+      if (force_nb) {
+        if (idx <= force_nb) { best = cost; best_cap = cap; best_T = T; best_load = mx; break; }
+        continue;
+      }
       if (cost < best) { best = cost; best_cap = cap; best_T = T; best_load = mx; }
     }
   }
   if (best_cap == 0) return 0;
+  // coarse cases (few splits per position, e.g. batch 128 with two M-tiles per position) do not come out even: keep the
+  // uniform grid unless the modelled load of the most loaded CU is within 12 % of the mean (sweeps with a forced target excepted)
+  {
+    long nblk = 0;
+    for (int c = 0; c < ncls; ++c)
+      for (int pos = 0; pos < npos[c]; ++pos) {
+        int sp = (int)(nvk[c][pos] / best_T + 0.5);
+        sp = sp < 1 ? 1 : sp > best_cap ? best_cap : sp;
+        if (sp > nvk[c][pos]) sp = nvk[c][pos];
+        nblk += (long)sp * r * ntn;
+      }
+    const double mean = ((double)total + OVH * (double)nblk) / NCU;
+    if (svs_tune(SVS_TUNE_CONV_BALANCE) < 16 && best_load > 1.12 * mean) return 0;
+  }
   int S = 1;
   unsigned at = 0;
   for (int c = 0; c < 4; ++c) {
