@@ -46,13 +46,13 @@ __device__ __forceinline__ void bf_static_for(F&& f) {          // f(integral_co
 enum { BF_GATHER = 0, BF_PARITY = 1 };
 __device__ __forceinline__ int swz16(int row, int chunk) { return chunk ^ ((row >> 1) & 3); }
 
-template <int MODE, int BM, int BN, int WM, int WN>
+template <int MODE, int BM, int BN, int WM, int WN, int KB = 1>      // KB: K-tiles (32 channels of one tap each) per barrier
 __global__ __launch_bounds__(256) void conv_gemm_bf16_kernel(ConvBf16Args p) {
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
   constexpr int RA = (BM + 63) / 64, RB = (BN + 63) / 64;
   static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "tile");
-  __shared__ __attribute__((aligned(16))) float As[2][BM * 16];     // 64-byte rows (32 bf16)
-  __shared__ __attribute__((aligned(16))) float Bs[2][BN * 16];
+  __shared__ __attribute__((aligned(16))) float As[2][KB][BM * 16];     // 64-byte rows (32 bf16)
+  __shared__ __attribute__((aligned(16))) float Bs[2][KB][BN * 16];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave / WN, wn = wave % WN, lrow = lane & 15, q = lane >> 4;
   int ph = 0, pw = 0, nth = 5, ntw = 5, Ha, Wa;
@@ -108,38 +108,48 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_kernel(ConvBf16Args p) {
   const long shift_px = (MODE == BF_GATHER) ? (2L * p.W + 2) * p.ldx : (1L * p.W + 1) * p.ldx;
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x - shift_px), 0, OOB, 0x00020000);
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wp, 0, OOB, 0x00020000);
-  // DEPTH register sets: the request for K-tile kt + DEPTH is issued when K-tile kt starts, so an operand has DEPTH - 1 tile
-  // times to arrive before it is written to LDS -- a bf16 K-tile is 8..16 MFMAs per wave (128..256 cycles), far shorter than an
-  // L2 round trip, and with one tile ahead the loop ran at load latency (2 us per K-tile)
-  constexpr int DEPTH = 3;
-  f32x4 ra[DEPTH][RA], rb[DEPTH][RB];
-  auto load_tile = [&](int kt, auto setc) __attribute__((always_inline)) {      // tap outer, channel chunk inner
+  // A "step" is KB consecutive K-tiles behind ONE barrier: a bf16 K-tile is only TM * TN MFMAs of 16 cycles per wave (128-256
+  // cycles), far less than a barrier plus an LDS round trip (rocprofv3 at 216 tiles, one K-tile per barrier: MFMA-busy
+  // 0.10-0.23, waves parked on waitcnt / barriers 0.41-0.63 of their cycles).  Two register sets of a whole step each: the
+  // request for step s + 2 is issued when step s starts, so an operand has a full step to arrive before it goes to LDS.
+  f32x4 ra[2][KB][RA], rb[2][KB][RB];
+  auto load_step = [&](int kt0, auto setc) __attribute__((always_inline)) {      // tap outer, channel chunk inner; past kt_end: zeros
     constexpr int set_ = decltype(setc)::value;
-    const int tap = kt / cpt, cc = kt - tap * cpt;
-    const int th = (ntw == 5) ? tap / 5 : (ntw == 3) ? tap / 3 : tap >> 1;
-    const int tw = tap - th * ntw;
-    const int pix = (MODE == BF_GATHER) ? th * p.W + tw : (2 - th) * p.W + (2 - tw);
-    const int soff_a = __builtin_amdgcn_readfirstlane((int)((pix * p.ldx + (cc << 5)) * 2));
-    const int soff_b = __builtin_amdgcn_readfirstlane((int)(((long)tap * p.C + (cc << 5)) * 2));
 #pragma unroll
-    for (int r = 0; r < RA; ++r) {
-      const unsigned vo = ((a_mask[r] >> tap) & 1u) ? a_voff[r] : OOB;
-      ra[set_][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)vo, soff_a, 0));
+    for (int u = 0; u < KB; ++u) {
+      const int kt = kt0 + u;
+      const bool live = kt < kt_end;                          // (block-uniform)
+      const int ktc = live ? kt : kt_begin;
+      const int tap = ktc / cpt, cc = ktc - tap * cpt;
+      const int th = (ntw == 5) ? tap / 5 : (ntw == 3) ? tap / 3 : tap >> 1;
+      const int tw = tap - th * ntw;
+      const int pix = (MODE == BF_GATHER) ? th * p.W + tw : (2 - th) * p.W + (2 - tw);
+      const int soff_a = __builtin_amdgcn_readfirstlane((int)((pix * p.ldx + (cc << 5)) * 2));
+      const int soff_b = __builtin_amdgcn_readfirstlane((int)(((long)tap * p.C + (cc << 5)) * 2));
+#pragma unroll
+      for (int r = 0; r < RA; ++r) {
+        const unsigned vo = (live && ((a_mask[r] >> tap) & 1u)) ? a_voff[r] : OOB;
+        ra[set_][u][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)vo, soff_a, 0));
+      }
+#pragma unroll
+      for (int r = 0; r < RB; ++r)
+        rb[set_][u][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, live ? (int)b_voff[r] : (int)OOB, soff_b, 0));
     }
-#pragma unroll
-    for (int r = 0; r < RB; ++r) rb[set_][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (int)b_voff[r], soff_b, 0));
   };
-  auto store_tile = [&](int buf, auto setc) __attribute__((always_inline)) {
+  auto store_step = [&](int buf, auto setc) __attribute__((always_inline)) {
     constexpr int set_ = decltype(setc)::value;
 #pragma unroll
-    for (int r = 0; r < RA; ++r) {
-      const int row = (t >> 2) + 64 * r;
-      if (BM % 64 == 0 || row < BM) *(f32x4*)(&As[buf][row * 16 + swz16(row, chunk) * 4]) = ra[set_][r];
-    }
+    for (int u = 0; u < KB; ++u) {
 #pragma unroll
-    for (int r = 0; r < RB; ++r) {
-      const int row = (t >> 2) + 64 * r;
-      if (BN % 64 == 0 || row < BN) *(f32x4*)(&Bs[buf][row * 16 + swz16(row, chunk) * 4]) = rb[set_][r];
+      for (int r = 0; r < RA; ++r) {
+        const int row = (t >> 2) + 64 * r;
+        if (BM % 64 == 0 || row < BM) *(f32x4*)(&As[buf][u][row * 16 + swz16(row, chunk) * 4]) = ra[set_][u][r];
+      }
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+        const int row = (t >> 2) + 64 * r;
+        if (BN % 64 == 0 || row < BN) *(f32x4*)(&Bs[buf][u][row * 16 + swz16(row, chunk) * 4]) = rb[set_][u][r];
+      }
     }
   };
   f32x4 acc[TM][TN];
@@ -147,32 +157,37 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_kernel(ConvBf16Args p) {
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  bf_static_for<DEPTH>([&](auto dc) { if (kt_begin + decltype(dc)::value < kt_end) load_tile(kt_begin + decltype(dc)::value, dc); });
-  if (kt_begin < kt_end) store_tile(0, std::integral_constant<int, 0>{});
+  const int nstep = (kt_end - kt_begin + KB - 1) / KB;
+  if (nstep > 0) load_step(kt_begin, std::integral_constant<int, 0>{});
+  if (nstep > 1) load_step(kt_begin + KB, std::integral_constant<int, 1>{});
+  if (nstep > 0) store_step(0, std::integral_constant<int, 0>{});
   __syncthreads();
-  for (int kt = kt_begin; kt < kt_end; kt += DEPTH) {
-    bf_static_for<DEPTH>([&](auto dc) {
+  for (int s0 = 0; s0 < nstep; s0 += 2) {
+    bf_static_for<2>([&](auto dc) {
       constexpr int d_ = decltype(dc)::value;
-      const int cur = kt + d_;
-      if (cur < kt_end) {                                     // (block-uniform)
-        const int buf = (cur - kt_begin) & 1;
-        if (cur + DEPTH < kt_end) load_tile(cur + DEPTH, dc);  // set d_ is free: K-tile `cur` went to LDS one step ago
-        bf16x8 fa[TM], fb[TN];
+      const int st = s0 + d_;
+      if (st < nstep) {                                       // (block-uniform)
+        const int buf = d_;                                   // step st lives in LDS buffer st & 1 = d_ (s0 is even)
+        if (st + 2 < nstep) load_step(kt_begin + (st + 2) * KB, dc);      // register set d_ is free: step st went to LDS one step ago
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          const int row = wm * (TM * 16) + i * 16 + lrow;
-          fa[i] = __builtin_bit_cast(bf16x8, *(const f32x4*)(&As[buf][row * 16 + swz16(row, q) * 4]));
+        for (int u = 0; u < KB; ++u) {
+          bf16x8 fa[TM], fb[TN];
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const int row = wm * (TM * 16) + i * 16 + lrow;
+            fa[i] = __builtin_bit_cast(bf16x8, *(const f32x4*)(&As[buf][u][row * 16 + swz16(row, q) * 4]));
+          }
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const int row = wn * (TN * 16) + j * 16 + lrow;
+            fb[j] = __builtin_bit_cast(bf16x8, *(const f32x4*)(&Bs[buf][u][row * 16 + swz16(row, q) * 4]));
+          }
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);   // weights first: see the epilogue
         }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int row = wn * (TN * 16) + j * 16 + lrow;
-          fb[j] = __builtin_bit_cast(bf16x8, *(const f32x4*)(&Bs[buf][row * 16 + swz16(row, q) * 4]));
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);   // weights first: see the epilogue
-        if (cur + 1 < kt_end) store_tile(buf ^ 1, std::integral_constant<int, (d_ + 1) % DEPTH>{});
+        if (st + 1 < nstep) store_step(buf ^ 1, std::integral_constant<int, (d_ + 1) % 2>{});
         __syncthreads();
       }
     });
@@ -729,6 +744,17 @@ static Bf16Plan plan_bf16(int mode, long Mmax, int N, int nkt) {
     if (ks > cap) ks = cap;
     if (ks > 32) ks = 32;
   }
+  if (svs_tune_on(SVS_TUNE_BF16_CFG)) {                       // sweeps: 0 128x128, 1 128x64, 4 64x128 (where N allows)
+    const int c = (int)svs_tune(SVS_TUNE_BF16_CFG);
+    if (c == 0 && N % 128 == 0) { pl.cfg = 0; pl.BM = 128; pl.BN = 128; }
+    if (c == 1 && N % 64 == 0) { pl.cfg = 1; pl.BM = 128; pl.BN = 64; }
+    if (c == 4 && N % 128 == 0) { pl.cfg = 4; pl.BM = 64; pl.BN = 128; }
+    pl.mtiles = (Mmax + pl.BM - 1) / pl.BM;
+    const long blocks2 = pl.mtiles * (N / pl.BN) * pl.grid_y;
+    ks = 1;
+    if (blocks2 < 512) { ks = (int)((768 + blocks2 - 1) / blocks2); const int cap = nkt / 8 > 1 ? nkt / 8 : 1; if (ks > cap) ks = cap; if (ks > 32) ks = 32; }
+  }
+  if (svs_tune_on(SVS_TUNE_BF16_KSPLIT)) { const int f = (int)svs_tune(SVS_TUNE_BF16_KSPLIT); if (f >= 1 && f <= 32 && f <= nkt) ks = f; }   // sweeps
   pl.ksplit = ks;
   return pl;
 }
@@ -763,15 +789,21 @@ static int conv_bf16_run(int mode, const u16* x, long ldx, int B, int H, int W, 
     a.slab = (float*)ws;
   }
   dim3 grid((unsigned)(pl.mtiles * (N / pl.BN)), (unsigned)pl.ksplit, (unsigned)pl.grid_y);
-#define SVS_BF16_LAUNCH(MODE_) \
+#define SVS_BF16_LAUNCH_KB(MODE_) \
   switch (pl.cfg) { \
-    case 0: hipLaunchKernelGGL((conv_gemm_bf16_kernel<MODE_, 128, 128, 2, 2>), grid, dim3(256), 0, stream, a); break; \
-    case 1: hipLaunchKernelGGL((conv_gemm_bf16_kernel<MODE_, 128, 64, 2, 2>), grid, dim3(256), 0, stream, a); break; \
-    case 2: hipLaunchKernelGGL((conv_gemm_bf16_kernel<MODE_, 256, 32, 4, 1>), grid, dim3(256), 0, stream, a); break; \
-    case 3: hipLaunchKernelGGL((conv_gemm_bf16_kernel<MODE_, 256, 16, 4, 1>), grid, dim3(256), 0, stream, a); break; \
-    default: hipLaunchKernelGGL((conv_gemm_bf16_kernel<MODE_, 64, 128, 2, 2>), grid, dim3(256), 0, stream, a); break; \
+    case 0: hipLaunchKernelGGL((conv_gemm_bf16_kernel<MODE_, 128, 128, 2, 2, KB_>), grid, dim3(256), 0, stream, a); break; \
+    case 1: hipLaunchKernelGGL((conv_gemm_bf16_kernel<MODE_, 128, 64, 2, 2, KB_>), grid, dim3(256), 0, stream, a); break; \
+    case 2: hipLaunchKernelGGL((conv_gemm_bf16_kernel<MODE_, 256, 32, 4, 1, 1>), grid, dim3(256), 0, stream, a); break; \
+    case 3: hipLaunchKernelGGL((conv_gemm_bf16_kernel<MODE_, 256, 16, 4, 1, 1>), grid, dim3(256), 0, stream, a); break; \
+    default: hipLaunchKernelGGL((conv_gemm_bf16_kernel<MODE_, 64, 128, 2, 2, KB_>), grid, dim3(256), 0, stream, a); break; \
   }
+  // K-tiles per barrier: 2 by default; BF16_KB = 1 / 2 / 4 for sweeps
+  const int kb = svs_tune_on(SVS_TUNE_BF16_KB) ? (int)svs_tune(SVS_TUNE_BF16_KB) : 2;
+#define SVS_BF16_LAUNCH(MODE_) \
+  if (kb >= 4) { constexpr int KB_ = 4; SVS_BF16_LAUNCH_KB(MODE_) } else if (kb == 2) { constexpr int KB_ = 2; SVS_BF16_LAUNCH_KB(MODE_) } \
+  else { constexpr int KB_ = 1; SVS_BF16_LAUNCH_KB(MODE_) }
   if (mode == BF_GATHER) { SVS_BF16_LAUNCH(BF_GATHER) } else { SVS_BF16_LAUNCH(BF_PARITY) }
+#undef SVS_BF16_LAUNCH_KB
 #undef SVS_BF16_LAUNCH
   SVS_CHECK_LAUNCH("conv_gemm_bf16");
   if (pl.ksplit > 1) {

@@ -37,7 +37,7 @@ extern "C" const char* svs_last_error_string(void) { return g_err; }
 // ---------------------------------------------------------------------------------------------
 static const char* const TUNE_NAMES[SVS_TUNE_COUNT] = {
     "CONV_CFG", "CONV_KSPLIT", "CONV_WINDOW", "CONV_SKIP", "CONV_KORDER", "CONV_DIRECT", "SKIP_REDUCE", "WGRAD_CFG",
-    "WGRAD_KSPLIT", "WGRAD_SKIP", "WGRAD_WINDOW", "WGRAD_C1_VALU", "SIDE_PRIORITY", "TRAIN_UNFUSED", "TRAIN_ONE_STREAM", "CONV_PLAN", "MFMA_SPLIT", "CONV_BALANCE"};
+    "WGRAD_KSPLIT", "WGRAD_SKIP", "WGRAD_WINDOW", "WGRAD_C1_VALU", "SIDE_PRIORITY", "TRAIN_UNFUSED", "TRAIN_ONE_STREAM", "CONV_PLAN", "MFMA_SPLIT", "CONV_BALANCE", "CONV_C1_TILED", "BF16_KB", "BF16_CFG", "BF16_KSPLIT"};
 static std::atomic<long> g_tune[SVS_TUNE_COUNT];      // written by svs_tuning_set while compute threads read: relaxed atomics
 static std::once_flag g_tune_once;
 static void tune_load_env() {
@@ -656,6 +656,13 @@ static int train_backward_impl(const ParamView& v, float* grads, const float* mi
     if (rc) return rc;
     const View xi = (k == 1) ? View{const_cast<float*>(mix), 1} : cat_half(t.cat, g, k - 1, 1);
     const float* x = xi.p; const long ldx = xi.ld;
+    if (k == 1) {
+      // conv1 is the end of the pass: nothing is left for the main stream to run beside this weight gradient, so it runs there
+      // itself (a fork + join for it left the main stream idle for 44 us before Adam: the fork's start latency and the join)
+      if ((rc = svs_enc_block_bwd_weight(d_raw, N, B, g.h[k], g.w[k], N, x, ldx, g.h[k - 1], g.w[k - 1], C, G(4 * l), nullptr,
+                                         t.scratch, t.scratch_bytes, stream))) return rc;
+      continue;
+    }
     if ((rc = fork())) return rc;
     if ((rc = svs_enc_block_bwd_weight(d_raw, N, B, g.h[k], g.w[k], N, x, ldx, g.h[k - 1], g.w[k - 1], C, G(4 * l), nullptr,
                                        wscratch, wscratch_bytes, wstream))) return rc;

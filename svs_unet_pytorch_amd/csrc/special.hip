@@ -92,6 +92,79 @@ __global__ __launch_bounds__(256) void conv_c1_kernel(C1Args p) {
   }
 }
 
+// Tiled form of the same convolution.  The thread-per-pixel kernel above multiplies 25 x COUT values per thread behind scalar
+// weight loads (COUT x 25 weights do not fit the scalar registers: 25-50 dependent s_load rounds per wave) with one wave's worth
+// of work in flight per pixel row: 2.5-2.9 TB/s.  Here a persistent block owns runs of 4 x 64-output tiles: the (11 x 131)-sample
+// window of a tile is staged ONCE in LDS (requested one tile ahead), a thread is (pixel, group of 4 channels) with its 25 x 4
+// weights in registers for the whole launch, reads each window row of its pixel as three 8-byte LDS loads (the 4 or 8 lanes of
+// a pixel read the same address: broadcast; consecutive pixels are 2 floats apart: conflict-free) and stores its float4
+// directly -- the COUT/4 lanes of a pixel write one contiguous 64 / 128-byte run, so there is no LDS transpose of the output.
+template <int COUT>
+__global__ __launch_bounds__(256, COUT == 32 ? 3 : 2) void conv_c1_tiled_kernel(C1Args p, int tiles_h, int tiles_w) {   // 166 / 188 registers: three / two blocks per CU (the 16-channel form spills at three)
+  constexpr int G = COUT / 4, TOH = 4, TOW = 64;
+  constexpr int WH = 2 * TOH + 3, WWD = 2 * TOW + 4;          // 11 x 132 floats (131 used; even pitch keeps the 8-byte reads aligned)
+  constexpr int NW = WH * WWD, NST = (NW + 255) / 256;
+  constexpr int PASSES = TOH * TOW * G / 256;
+  constexpr unsigned OOB = 0x80000000u;
+  __shared__ __attribute__((aligned(16))) float win[NW];
+  const int t = threadIdx.x, cg = t % G, pl = t / G;
+  f32x4 wr[25];
+#pragma unroll
+  for (int tap = 0; tap < 25; ++tap)
+    wr[tap] = (f32x4){p.w[(cg * 4 + 0) * 25 + tap], p.w[(cg * 4 + 1) * 25 + tap], p.w[(cg * 4 + 2) * 25 + tap], p.w[(cg * 4 + 3) * 25 + tap]};
+  f32x4 b4 = {0.f, 0.f, 0.f, 0.f}, sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias) b4 = *(const f32x4*)(p.bias + cg * 4);
+  if (p.scale) { sc4 = *(const f32x4*)(p.scale + cg * 4); sh4 = *(const f32x4*)(p.shift + cg * 4); }
+  const int ntiles = p.B * tiles_h * tiles_w;
+  const int tile_lo = (int)((long)ntiles * blockIdx.x / gridDim.x), tile_hi = (int)((long)ntiles * (blockIdx.x + 1) / gridDim.x);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, OOB, 0x00020000);
+  float stage[NST];
+  auto fetch = [&](int tile) {            // the tile's input window, zero outside the image (out-of-range offset: no branches)
+    const int ow0 = (tile % tiles_w) * TOW, oh0 = ((tile / tiles_w) % tiles_h) * TOH;
+    const int img = (tile / (tiles_w * tiles_h)) * p.H * p.W;                    // (whole input < 2 GiB: checked on the host)
+#pragma unroll
+    for (int k = 0; k < NST; ++k) {
+      const int e = t + 256 * k, lh = e / WWD, lw = e - lh * WWD;
+      const int ih = 2 * oh0 - 2 + lh, iw = 2 * ow0 - 2 + lw;
+      const bool ok = e < NW && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+      stage[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, ok ? (int)((unsigned)(img + ih * p.W + iw) * 4u) : (int)OOB, 0, 0));
+    }
+  };
+  if (tile_lo < tile_hi) fetch(tile_lo);
+  for (int tile = tile_lo; tile < tile_hi; ++tile) {
+    const int ow0 = (tile % tiles_w) * TOW, oh0 = ((tile / tiles_w) % tiles_h) * TOH;
+    const long b = tile / (tiles_w * tiles_h);
+    __syncthreads();                                            // the previous tile's readers are done
+#pragma unroll
+    for (int k = 0; k < NST; ++k) { const int e = t + 256 * k; if (e < NW) win[e] = stage[k]; }
+    __syncthreads();
+    if (tile + 1 < tile_hi) fetch(tile + 1);                    // in flight while this tile is computed
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+      const int px = ps * (256 / G) + pl, lr = px / TOW, lc = px - lr * TOW;
+      f32x4 acc = b4;
+#pragma unroll
+      for (int kh = 0; kh < 5; ++kh) {
+        const float2* row = (const float2*)(&win[(2 * lr + kh) * WWD + 2 * lc]);
+        const float2 a = row[0], c = row[1], e = row[2];
+        acc += wr[kh * 5 + 0] * a.x; acc += wr[kh * 5 + 1] * a.y; acc += wr[kh * 5 + 2] * c.x; acc += wr[kh * 5 + 3] * c.y;
+        acc += wr[kh * 5 + 4] * e.x;
+      }
+      if (p.scale) {
+        acc = acc * sc4 + sh4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] = acc[k] > 0.f ? acc[k] : acc[k] * p.slope;
+      }
+      const int oh = oh0 + lr, ow = ow0 + lc;
+      if (oh < p.Ho && ow < p.Wo) {
+        float* dst = p.y + chan_off((b * p.Ho + oh) * p.Wo + ow, p.ldy, cg, G / 2, p.half);
+        if (p.accumulate) acc += *(const f32x4*)dst;
+        *(f32x4*)dst = acc;
+      }
+    }
+  }
+}
+
 int svs_conv_c1_run(const float* x, int B, int H, int W, const float* w, const float* bias, const float* scale,
                     const float* shift, float slope, float* y, long ldy, int N, int accumulate, hipStream_t stream,
                     const char* who, long half) {
@@ -102,6 +175,20 @@ int svs_conv_c1_run(const float* x, int B, int H, int W, const float* w, const f
   const long total = (long)B * a.Ho * a.Wo;
   SVS_REQUIRE(total < (1L << 31), "%s: %ld output pixels need 64-bit indices; split the batch", who, total);
   SVS_REQUIRE((long)B * H * W * 4 < (1L << 31), "%s: the input must span < 2 GiB (32-bit buffer offsets); split the batch", who);
+  // same-device A/B at batch 64 (tools/ab_c1_tiled.py): 32 channels (deconv6 backward-data) 50.0 -> 44.4 us, 16 channels
+  // (conv1 forward) 25.9 -> 29.9 us -- with 36 registers the thread-per-pixel form runs 8 waves per SIMD there
+  const long tiled = svs_tune(SVS_TUNE_CONV_C1_TILED);       // 0: never, 2: always (A/B runs, tests)
+  if (tiled == 2 || (tiled != 0 && N == 32)) {
+    const int tiles_h = (a.Ho + 3) / 4, tiles_w = (a.Wo + 63) / 64;
+    const long ntiles = (long)B * tiles_h * tiles_w;
+    SVS_REQUIRE(ntiles < (1L << 31), "%s: too many tiles", who);
+    const long cap = N == 32 ? 768 : 512;                   // persistent: every block resident (three / two per CU), weights loaded once per block
+    const int grid = (int)(ntiles < cap ? ntiles : cap);
+    if (N == 16) hipLaunchKernelGGL(conv_c1_tiled_kernel<16>, dim3(grid), dim3(256), 0, stream, a, tiles_h, tiles_w);
+    else hipLaunchKernelGGL(conv_c1_tiled_kernel<32>, dim3(grid), dim3(256), 0, stream, a, tiles_h, tiles_w);
+    SVS_CHECK_LAUNCH("conv_c1_tiled");
+    return SVS_OK;
+  }
   const int grid = (int)((total + 255) / 256);
   if (N == 16) hipLaunchKernelGGL(conv_c1_kernel<16>, dim3(grid), dim3(256), 0, stream, a);
   else hipLaunchKernelGGL(conv_c1_kernel<32>, dim3(grid), dim3(256), 0, stream, a);

@@ -189,8 +189,10 @@ def test_mfma_split_mode_accuracy(kind, B, H, W, C, N, report, tune):
     assert report(f"split-bf16 mean error relative to the fp32 MFMA's ({kind} C{C} N{N})", (esp.mean() / e32.mean()).item(), 1.1)
 
 
-def test_enc_block_fwd_c1(report):
-    for (B, H, W, N) in ((2, 64, 32, 16), (1, 33, 17, 16), (2, 32, 32, 32), (3, 21, 9, 32), (1, 4, 2, 16)):
+@pytest.mark.parametrize("form", [0, 2], ids=["thread-per-pixel", "tiled"])
+def test_enc_block_fwd_c1(form, report, tune):
+    tune("CONV_C1_TILED", form)          # both forms of the single-channel convolution at every size (the planner picks per channel count)
+    for (B, H, W, N) in ((2, 64, 32, 16), (1, 33, 17, 16), (2, 32, 32, 32), (3, 21, 9, 32), (1, 4, 2, 16), (1, 300, 140, 32)):
         x = rnd((B, 1, H, W), 20, 0, 1)
         w = rnd((N, 1, 5, 5), 21, -0.2, 0.2)
         b = rnd((N,), 22)
