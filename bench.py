@@ -331,6 +331,36 @@ def eval_record(model, dev, B=16, steps=30, warmup=5):
     return out
 
 
+def full_objective_record(model, dev, B=64, steps=15, warmup=4):
+    """The reference's FULL training objective (train.py:287-296: alpha_L1 * L1 + alpha_MR * MR-STFT of the re-synthesised
+    waveforms, its default) as one train step at batch B: two `specific_istft`, the three-resolution STFT loss with gradient, the
+    transposed iSTFT into the mask logit, then the same backward + Adam as the L1 step.  Not what `value` measures (BASELINE's
+    workload is the L1-loss step); reported beside it."""
+    from svs_unet_pytorch_amd.model import ALPHA_MR
+    H, W = 512, 128
+    mix = torch.empty((B, 1, H, W), device=dev)
+    voc = torch.empty_like(mix)
+    _lib.check(_lib.lib().svs_fill_tiles(mix.data_ptr(), voc.data_ptr(), B, H, W, 40_000, _lib.stream_ptr()), "svs_fill_tiles")
+    mph = (torch.rand((B, 1, H, W), device=dev) - 0.5) * 6.2831853
+    vph = (torch.rand((B, 1, H, W), device=dev) - 0.5) * 6.2831853
+    model.train()
+    out = {}
+    for name, kw in (("l1_only", {}), ("l1_plus_mrstft", dict(mix_phase=mph, voc_phase=vph, alpha_mr=ALPHA_MR))):
+        for _ in range(warmup):
+            model.train_step(mix, voc, loss_scale=ALPHA_L1, **kw)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            model.train_step(mix, voc, loss_scale=ALPHA_L1, **kw)
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / steps
+        out[name] = {"ms_per_step": round(ms, 4), "tiles_per_s": round(B / ms * 1e3, 1)}
+    out["batch"] = B
+    out["mrstft_part_ms"] = round(out["l1_plus_mrstft"]["ms_per_step"] - out["l1_only"]["ms_per_step"], 4)
+    model._ws.pop(("mr", B, W, 768), None)
+    return out
+
+
 def strong_record(model, dev, world, rank, grad_sync, global_batch=512, steps=6, warmup=2):
     """Train step at a FIXED global batch of 512 tiles split over the ranks (north_star's strong-scaling target is quoted on
     this): per-GPU batch 512 / world.  Rank-local timing (the caller reduces with MAX over ranks when world > 1)."""
@@ -557,6 +587,10 @@ def main():
                 if args.mode == "train":
                     res["optional_mfma_split"] = split_mode_record(model, dev, B)
                     res["eval_b16"] = eval_record(model, dev)                  # BASELINE configs[1]
+                    try:
+                        res["full_objective"] = full_objective_record(model, dev, B)     # train.py's default objective (L1 + MR-STFT)
+                    except Exception as e:
+                        res["full_objective_error"] = str(e)[:200]
                 try:
                     sys.path.insert(0, os.path.join(ROOT, "tools"))
                     from signal_bench import signal_record

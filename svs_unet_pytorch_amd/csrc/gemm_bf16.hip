@@ -755,6 +755,17 @@ static Bf16Plan plan_bf16(int mode, long Mmax, int N, int nkt) {
     if (blocks2 < 512) { ks = (int)((768 + blocks2 - 1) / blocks2); const int cap = nkt / 8 > 1 ? nkt / 8 : 1; if (ks > cap) ks = cap; if (ks > 32) ks = 32; }
   }
   if (svs_tune_on(SVS_TUNE_BF16_KSPLIT)) { const int f = (int)svs_tune(SVS_TUNE_BF16_KSPLIT); if (f >= 1 && f <= 32 && f <= nkt) ks = f; }   // sweeps
+  if (svs_tune_on(SVS_TUNE_BF16_CFG)) {                       // sweeps: 0 128x128, 1 128x64, 4 64x128 (where N allows)
+    const int c = (int)svs_tune(SVS_TUNE_BF16_CFG);
+    if (c == 0 && N % 128 == 0) { pl.cfg = 0; pl.BM = 128; pl.BN = 128; }
+    if (c == 1 && N % 64 == 0) { pl.cfg = 1; pl.BM = 128; pl.BN = 64; }
+    if (c == 4 && N % 128 == 0) { pl.cfg = 4; pl.BM = 64; pl.BN = 128; }
+    pl.mtiles = (Mmax + pl.BM - 1) / pl.BM;
+    const long blocks2 = pl.mtiles * (N / pl.BN) * pl.grid_y;
+    ks = 1;
+    if (blocks2 < 512) { ks = (int)((768 + blocks2 - 1) / blocks2); const int cap = nkt / 8 > 1 ? nkt / 8 : 1; if (ks > cap) ks = cap; if (ks > 32) ks = 32; }
+  }
+  if (svs_tune_on(SVS_TUNE_BF16_KSPLIT)) { const int f = (int)svs_tune(SVS_TUNE_BF16_KSPLIT); if (f >= 1 && f <= 32 && f <= nkt) ks = f; }   // sweeps
   pl.ksplit = ks;
   return pl;
 }

@@ -35,6 +35,22 @@ def timed(fn, reps=20, warm=3):
     return e0.elapsed_time(e1) / reps
 
 
+def timed_isolated(fn, reps=10):
+    """One launch at a time on an idle device (synchronise, event, launch, event): start-to-end of a single launch plus the
+    event overhead -- the upper companion of `timed`, whose back-to-back launches overlap each other's ramp-up and tail."""
+    fn()
+    tot = 0.0
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        tot += e0.elapsed_time(e1)
+    return tot / reps
+
+
 def signal_record(seconds=240.0, rate=44100, batch=64):
     n = int(seconds * rate)
     L = _lib.lib()
@@ -52,13 +68,19 @@ def signal_record(seconds=240.0, rate=44100, batch=64):
     inv = lambda: L.svs_istft_tiles(tiles.data_ptr(), n_tiles * 512 * 128, 128, 512, 1, mask.data_ptr(), 0, ph.data_ptr(), 1, C, 1024, 768, T,
                                     out.data_ptr(), part2.data_ptr(), _lib.stream_ptr())
     ms_f, ms_i = timed(fwd), timed(inv)
+    iso_f, iso_i = timed_isolated(fwd), timed_isolated(inv)
     bytes_f = C * (n * 4 + T * 512 * 4 + T * 513 * 8)
     bytes_i = C * (T * 512 * 4 * 2 + T * 513 * 8 + 768 * (T - 1) * 4)
     rec = {"audio_seconds": seconds, "channels": C, "frames_per_channel": T,
            "stft": {"ms": round(ms_f, 4), "algorithmic_MB": round(bytes_f / 1e6, 1), "GBps": round(bytes_f / ms_f / 1e6, 1),
                     "frac_of_6.29TBps": round(bytes_f / ms_f / 1e9 / HBM_ACHIEVABLE_TBS, 3)},
            "istft": {"ms": round(ms_i, 4), "algorithmic_MB": round(bytes_i / 1e6, 1), "GBps": round(bytes_i / ms_i / 1e6, 1),
-                     "frac_of_6.29TBps": round(bytes_i / ms_i / 1e9 / HBM_ACHIEVABLE_TBS, 3)}}
+                     "frac_of_6.29TBps": round(bytes_i / ms_i / 1e9 / HBM_ACHIEVABLE_TBS, 3)},
+           "timing": "ms = HIP events around 20 back-to-back launches on the launch stream (what a pipeline of launches sustains: successive "
+                     "launches overlap each other's ramp-up and tail); ms_single_launch = one launch at a time on an idle device, start to end "
+                     "incl. the event pair (what rocprofv3's per-kernel average of profiles/r0N_signal_*_kernel_stats.csv corresponds to)"}
+    rec["stft"]["ms_single_launch"] = round(iso_f, 4)
+    rec["istft"]["ms_single_launch"] = round(iso_i, 4)
     # training-side pieces at batch B: specific_istft (train.py:33-60) and the MR-STFT loss with gradient (train.py:293)
     B, Tt = batch, 128
     mag = torch.rand((B, 1, 512, Tt), device="cuda")
