@@ -51,7 +51,9 @@ const char* svs_last_error_string(void);
  * inference calls too), MFMA_SPLIT (1: the fp32 GEMM kernels form their products on the bf16 MFMA from exact three-limb
  * splits of the fp32 operands -- fp32-accurate, see csrc/mfma_split.h; default off), CONV_BALANCE (0: one K-split count per
  * layer instead of per-position counts on the tap-skipping layers), CONV_C1_TILED (0: the thread-per-pixel form of the
- * single-channel convolution), BF16_KB (K-tiles per barrier of the bf16 GEMM: 1, 2 or 4), or "*" for all; value -1 = planner
+ * single-channel convolution), BF16_KB (K-tiles per barrier of the bf16 GEMM: 1, 2 or 4), BF16_CFG / BF16_KSPLIT (its tile / K-split),
+ * CONV_PF / WGRAD_PF (K-tiles the fp32 conv / weight-gradient GEMMs request ahead: 1 or 2; CONV_PF 3: on every tile shape),
+ * or "*" for all; value -1 = planner
  * default ("*", -1: every switch back to what the environment gave at load).  The boolean switches (SKIP_REDUCE,
  * WGRAD_C1_VALU, TRAIN_UNFUSED, TRAIN_ONE_STREAM, MFMA_SPLIT) are ON for values > 0 only -- 0 and -1 both mean off; the
  * others are valued (0 is a value).  The table is initialised from the environment (SVS_<NAME>) at first use; no compute

@@ -74,7 +74,7 @@ __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >>
 // for all of them at once and its K-tiles are skipped outright (no loads, no MFMAs): -30% work on the 8x2 level,
 // -15% on 16x4.  Skipped products are exact zeros, so results do not change.  Needs tap-outer K order and C/16 a
 // power of two.
-template <int MODE, int BM, int BN, int WM, int WN, bool SKIP = false, bool SPLIT = false>     // SPLIT: mfma_split.h (optional mode)
+template <int MODE, int BM, int BN, int WM, int WN, bool SKIP = false, bool SPLIT = false, int PF = 1>     // SPLIT: mfma_split.h (optional mode); PF: K-tiles requested ahead
 __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs p, std::conditional_t<SKIP, ConvBal, ConvNoBal> bal) {
   constexpr int TM = BM / WM / 16;
   constexpr int TN = BN / WN / 16;
@@ -220,9 +220,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs p, std::con
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wp, 0, OOB, 0x00020000);
 
   f32x4 ra[RA], rb[RB];
+  f32x4 ra2[PF == 2 ? RA : 1], rb2[PF == 2 ? RB : 1];       // PF = 2: a second register set (requests two K-tiles ahead)
   // K-tile kt -> (tap, channel chunk), from block-uniform values only (plain scalar arithmetic: mutable loader
   // state captured by the lambdas below used to end up in scratch memory, with waterfall loops around the loads)
-  auto load_tile = [&](int kt) {
+  auto load_tile_to = [&](int kt, f32x4 (&ra)[RA], f32x4 (&rb)[RB]) __attribute__((always_inline)) {
     int tap, cc;
     if (SKIP || !p.tap_inner) {            // tap outer, chunk inner
       if (p.cpt_shift >= 0) { tap = kt >> p.cpt_shift; cc = kt & (cpt - 1); }
@@ -245,7 +246,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs p, std::con
     for (int r = 0; r < RB; ++r)
       rb[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (int)b_voff[r], soff_b, 0));
   };
-  auto store_tile = [&](int buf) {       // unconditional when the tile height is a multiple of 64 rows (no exec-mask branches)
+  auto load_tile = [&](int kt) __attribute__((always_inline)) { load_tile_to(kt, ra, rb); };
+  auto store_tile_from = [&](int buf, const f32x4 (&ra)[RA], const f32x4 (&rb)[RB]) __attribute__((always_inline)) {       // unconditional when the tile height is a multiple of 64 rows (no exec-mask branches)
 #pragma unroll
     for (int r = 0; r < RA; ++r) {
       const int row = (t >> 2) + 64 * r;
@@ -258,6 +260,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs p, std::con
     }
   };
 
+  auto store_tile = [&](int buf) __attribute__((always_inline)) { store_tile_from(buf, ra, rb); };
   f32x4 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -274,7 +277,62 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs p, std::con
     const int nk = (tp + 1 + __builtin_ctz(rest)) << p.cpt_shift;
     return nk < kt_end ? nk : kt_end;
   };
+  auto multiply = [&](int buf) __attribute__((always_inline)) {
+    f32x4 fa[TM], fb[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int row = wm * (TM * 16) + i * 16 + lrow;
+      fa[i] = *(const f32x4*)(&As[buf][row * 16 + swz(row, q) * 4]);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int row = wn * (TN * 16) + j * 16 + lrow;
+      fb[j] = *(const f32x4*)(&Bs[buf][row * 16 + swz(row, q) * 4]);
+    }
+    if constexpr (SPLIT) {
+      SvsSplitA sa[TM];
+      SvsSplitB sb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) sa[i] = svs_split_a(fa[i][0], fa[i][1], fa[i][2], fa[i][3]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) sb[j] = svs_split_b(fb[j][0], fb[j][1], fb[j][2], fb[j][3]);
+      svs_mma_split<TM, TN>(acc, sa, sb);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][k], fb[j][k], acc[i][j], 0, 0, 0);
+    }
+  };
   int kt_cur = first_valid(kt_begin);
+  if constexpr (PF == 2) {
+    // Two K-tiles in flight: the request for tile n + 2 goes out when tile n starts, so an operand has two tile times to arrive
+    // before it is written to LDS.  For launches with few resident waves per CU (small batches: every block of a deep layer is a
+    // chain of 25-100 short K-tiles) one tile time -- 512 MFMA cycles -- is less than an L2 / Infinity-Cache round trip.
+    int kt_n1 = first_valid(kt_cur + 1);
+    if (kt_cur < kt_end) load_tile_to(kt_cur, ra, rb);
+    if (kt_n1 < kt_end) load_tile_to(kt_n1, ra2, rb2);
+    if (kt_cur < kt_end) store_tile_from(0, ra, rb);
+    __syncthreads();
+    while (kt_cur < kt_end) {
+      int kt_n2 = first_valid(kt_n1 + 1);                     // tile in LDS buffer 0; set 1 holds n1; set 0 is free
+      if (kt_n2 < kt_end) load_tile_to(kt_n2, ra, rb);
+      multiply(0);
+      if (kt_n1 < kt_end) store_tile_from(1, ra2, rb2);
+      __syncthreads();
+      kt_cur = kt_n1; kt_n1 = kt_n2;
+      if (kt_cur >= kt_end) break;
+      kt_n2 = first_valid(kt_n1 + 1);                         // tile in LDS buffer 1; set 0 holds n1; set 1 is free
+      if (kt_n2 < kt_end) load_tile_to(kt_n2, ra2, rb2);
+      multiply(1);
+      if (kt_n1 < kt_end) store_tile_from(0, ra, rb);
+      __syncthreads();
+      kt_cur = kt_n1; kt_n1 = kt_n2;
+    }
+  } else {
   if (kt_cur < kt_end) {
     load_tile(kt_cur);
     store_tile(0);
@@ -316,6 +374,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs p, std::con
     }
     if (more) store_tile(buf ^ 1);
     __syncthreads();
+  }
   }
 
   // ---- epilogue: C/D map of the 16x16 MFMA: col = lane & 15, row = 4*(lane>>4) + reg ------------
@@ -795,7 +854,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
 }
 
 // ---- host side ---------------------------------------------------------------------------------
-struct ConvPlan { int cfg; int BM, BN; int ksplit; long mtiles; int grid_y; };
+struct ConvPlan { int cfg; int BM, BN; int ksplit; long mtiles; int grid_y; int pf; };
 
 // `inference`: the call has the folded-BatchNorm epilogue (eval forward).  Those calls run at the serving batch sizes (1..16
 // tiles, BASELINE configs[0..1]) and take the rules of the batch-16 sweep; the training calls keep the batch-64 table (same-device
@@ -854,6 +913,17 @@ static ConvPlan plan_conv(int mode, long Mmax, int N, int nkt_min, bool narrow =
   }
   if (svs_tune_on(SVS_TUNE_CONV_KSPLIT)) { int f = (int)svs_tune(SVS_TUNE_CONV_KSPLIT); if (f >= 1 && f <= nkt_min) ks = f; }
   pl.ksplit = ks;
+  // K-tiles requested ahead: two on the 64-row tiles (same-device A/B of tools/ab_tune.py CONV_PF 1 2: train step at batch 64
+  // 3.530 -> 3.454 ms, eval forward 0.388 -> 0.379 ms at batch 16 and 1.030 -> 0.994 ms at batch 64: with 60-100 registers these
+  // tiles keep their occupancy, and one tile time -- 512 MFMA cycles -- is less than an L2 / Infinity-Cache round trip under load)
+  // (the 128x64 / 256x32 / 256x16 tiles: another -6 us on the train step, CONV_PF 2 against 3; the 128x128 and 32x128 tiles keep
+  //  one tile ahead: at 164 registers a second set costs the 128x128 tile its third resident block)
+  pl.pf = (pl.cfg == 5 || pl.cfg == 6 || (pl.cfg >= 1 && pl.cfg <= 3)) ? 2 : 1;
+  // CONV_PF (A/B runs): 1 = one tile ahead everywhere; 2 = two ahead on the 64-row tiles only; 3 = on every tile that has the variant
+  if (svs_tune_on(SVS_TUNE_CONV_PF)) {
+    const long f = svs_tune(SVS_TUNE_CONV_PF);
+    pl.pf = (f >= 2 && (pl.cfg == 5 || pl.cfg == 6)) || (f == 3 && pl.cfg >= 1 && pl.cfg <= 3) ? 2 : 1;
+  }
   return pl;
 }
 
@@ -863,22 +933,38 @@ static void launch_conv_gemm_cfg(const ConvGemmArgs& a, const ConvPlan& pl, dim3
   if (skip) {                                // batch-innermost rows + padding-tap skipping (deep levels)
     switch (pl.cfg) {
       case 0: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 128, 128, 2, 2, true, SPLIT>), grid, block, 0, stream, a, bal); break;
-      case 1: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 128, 64, 2, 2, true, SPLIT>), grid, block, 0, stream, a, bal); break;
+      case 1: if (pl.pf == 2) hipLaunchKernelGGL((conv_gemm_kernel<MODE, 128, 64, 2, 2, true, SPLIT, 2>), grid, block, 0, stream, a, bal);
+              else hipLaunchKernelGGL((conv_gemm_kernel<MODE, 128, 64, 2, 2, true, SPLIT>), grid, block, 0, stream, a, bal);
+              break;
       case 4: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 32, 128, 1, 4, true, SPLIT>), grid, block, 0, stream, a, bal); break;
-      case 6: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 64, 128, 2, 2, true, SPLIT>), grid, block, 0, stream, a, bal); break;
-      default: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 64, 64, 2, 2, true, SPLIT>), grid, block, 0, stream, a, bal); break;
+      case 6: if (pl.pf == 2) hipLaunchKernelGGL((conv_gemm_kernel<MODE, 64, 128, 2, 2, true, SPLIT, 2>), grid, block, 0, stream, a, bal);
+              else hipLaunchKernelGGL((conv_gemm_kernel<MODE, 64, 128, 2, 2, true, SPLIT>), grid, block, 0, stream, a, bal);
+              break;
+      default: if (pl.pf == 2) hipLaunchKernelGGL((conv_gemm_kernel<MODE, 64, 64, 2, 2, true, SPLIT, 2>), grid, block, 0, stream, a, bal);
+               else hipLaunchKernelGGL((conv_gemm_kernel<MODE, 64, 64, 2, 2, true, SPLIT>), grid, block, 0, stream, a, bal);
+               break;
     }
     return;
   }
   const ConvNoBal nb{};
   switch (pl.cfg) {
     case 0: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 128, 128, 2, 2, false, SPLIT>), grid, block, 0, stream, a, nb); break;
-    case 1: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 128, 64, 2, 2, false, SPLIT>), grid, block, 0, stream, a, nb); break;
-    case 2: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 256, 32, 4, 1, false, SPLIT>), grid, block, 0, stream, a, nb); break;
-    case 3: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 256, 16, 4, 1, false, SPLIT>), grid, block, 0, stream, a, nb); break;
+    case 1: if (pl.pf == 2) hipLaunchKernelGGL((conv_gemm_kernel<MODE, 128, 64, 2, 2, false, SPLIT, 2>), grid, block, 0, stream, a, nb);
+            else hipLaunchKernelGGL((conv_gemm_kernel<MODE, 128, 64, 2, 2, false, SPLIT>), grid, block, 0, stream, a, nb);
+            break;
+    case 2: if (pl.pf == 2) hipLaunchKernelGGL((conv_gemm_kernel<MODE, 256, 32, 4, 1, false, SPLIT, 2>), grid, block, 0, stream, a, nb);
+            else hipLaunchKernelGGL((conv_gemm_kernel<MODE, 256, 32, 4, 1, false, SPLIT>), grid, block, 0, stream, a, nb);
+            break;
+    case 3: if (pl.pf == 2) hipLaunchKernelGGL((conv_gemm_kernel<MODE, 256, 16, 4, 1, false, SPLIT, 2>), grid, block, 0, stream, a, nb);
+            else hipLaunchKernelGGL((conv_gemm_kernel<MODE, 256, 16, 4, 1, false, SPLIT>), grid, block, 0, stream, a, nb);
+            break;
     case 4: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 32, 128, 1, 4, false, SPLIT>), grid, block, 0, stream, a, nb); break;
-    case 6: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 64, 128, 2, 2, false, SPLIT>), grid, block, 0, stream, a, nb); break;
-    default: hipLaunchKernelGGL((conv_gemm_kernel<MODE, 64, 64, 2, 2, false, SPLIT>), grid, block, 0, stream, a, nb); break;
+    case 6: if (pl.pf == 2) hipLaunchKernelGGL((conv_gemm_kernel<MODE, 64, 128, 2, 2, false, SPLIT, 2>), grid, block, 0, stream, a, nb);
+            else hipLaunchKernelGGL((conv_gemm_kernel<MODE, 64, 128, 2, 2, false, SPLIT>), grid, block, 0, stream, a, nb);
+            break;
+    default: if (pl.pf == 2) hipLaunchKernelGGL((conv_gemm_kernel<MODE, 64, 64, 2, 2, false, SPLIT, 2>), grid, block, 0, stream, a, nb);
+             else hipLaunchKernelGGL((conv_gemm_kernel<MODE, 64, 64, 2, 2, false, SPLIT>), grid, block, 0, stream, a, nb);
+             break;
   }
 }
 template <int MODE>

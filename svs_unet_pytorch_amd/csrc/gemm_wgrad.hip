@@ -43,7 +43,7 @@ template <> __device__ __forceinline__ void store_vec<2>(float* p, const float (
 // the 16 pixels of a K-tile are the SAME position (i, j) of 16 images.  A tap that falls into the zero padding at
 // that position does so for the whole tile; a K-tile none of whose N-tile taps is inside the image is skipped
 // outright (about a third of the tiles on the 8x2 level).  The per-tile pixel decode also becomes scalar.
-template <int BM, int BN, int WM, int WN, bool SKIP = false, bool SPLIT = false>     // SPLIT: mfma_split.h (optional mode)
+template <int BM, int BN, int WM, int WN, bool SKIP = false, bool SPLIT = false, int PF = 1>     // SPLIT: mfma_split.h (optional mode); PF: K-tiles requested ahead
 __global__ __launch_bounds__(256) void wgrad_gemm_kernel(WgradArgs p) {
   constexpr int TM = BM / WM / 16;
   constexpr int TN = BN / WN / 16;
@@ -162,7 +162,8 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(WgradArgs p) {
     return (int)p_end;
   };
   f32x4 ra[RA], rb[RB];
-  auto load_tile_skip = [&](int pk) {
+  f32x4 ra2[PF == 2 ? RA : 1], rb2[PF == 2 ? RB : 1];       // PF = 2: a second register set (requests two K-tiles ahead)
+  auto load_tile_skip = [&](int pk, f32x4 (&ra)[RA], f32x4 (&rb)[RB]) __attribute__((always_inline)) {
     int i, j, b0;
     position(pk, i, j, b0);
     const int soff_a = __builtin_amdgcn_readfirstlane((int)((((long)b0 * HsWs + (i * p.Ws + j)) * p.lds) * 4));
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(WgradArgs p) {
       rb[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rl_sh, (int)(ok ? b_voff_s[r] : OOB), soff_b, 0));
     }
   };
-  auto load_tile = [&](long pk) {      // must be called with pk advancing by 16 from p_begin
+  auto load_tile = [&](long pk, f32x4 (&ra)[RA], f32x4 (&rb)[RB]) __attribute__((always_inline)) {      // must be called with pk advancing by 16 from p_begin
     const int soff_a = (int)((pk - p_begin) * p.lds * 4);
     const int left = (int)(p_end - pk);          // rows of this tile inside the split (16 except in its last tile)
 #pragma unroll
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(WgradArgs p) {
     }
     advance();
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf, const f32x4 (&ra)[RA], const f32x4 (&rb)[RB]) __attribute__((always_inline)) {
 #pragma unroll
     for (int r = 0; r < RA; ++r)
       if (aok[r]) *(f32x4*)(&As[buf][ak[r] * LDA + ac[r] * 4]) = ra[r];
@@ -212,18 +213,7 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(WgradArgs p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  int pk = first_valid((int)p_begin);
-  if (pk < (int)p_end) {
-    if (SKIP) load_tile_skip(pk); else load_tile(pk);
-    store_tile(0);
-  }
-  __syncthreads();
-  for (int it = 0; pk < (int)p_end; ++it) {
-    const int buf = it & 1;
-    const int pkn = first_valid(pk + 16);
-    const bool more = pkn < (int)p_end;
-    if (more) { if (SKIP) load_tile_skip(pkn); else load_tile(pkn); }
-    pk = pkn;
+  auto multiply = [&](int buf) __attribute__((always_inline)) {
     if constexpr (SPLIT) {                     // the lane's four k of every tile row / column, split into bf16 limbs
       float ga[4][TM], gb[4][TN];
 #pragma unroll
@@ -256,8 +246,47 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(WgradArgs p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
     }
-    if (more) store_tile(buf ^ 1);
+  };
+  auto fetch = [&](int pkx, f32x4 (&xa)[RA], f32x4 (&xb)[RB]) __attribute__((always_inline)) { if (SKIP) load_tile_skip(pkx, xa, xb); else load_tile(pkx, xa, xb); };
+  int pk = first_valid((int)p_begin);
+  if constexpr (PF == 2) {
+    // two K-tiles in flight (see conv_gemm_kernel): the request for tile n + 2 goes out when tile n starts
+    int pk1 = first_valid(pk + 16);
+    if (pk < (int)p_end) fetch(pk, ra, rb);
+    if (pk1 < (int)p_end) fetch(pk1, ra2, rb2);
+    if (pk < (int)p_end) store_tile(0, ra, rb);
     __syncthreads();
+    while (pk < (int)p_end) {
+      int pk2 = first_valid(pk1 + 16);
+      if (pk2 < (int)p_end) fetch(pk2, ra, rb);
+      multiply(0);
+      if (pk1 < (int)p_end) store_tile(1, ra2, rb2);
+      __syncthreads();
+      pk = pk1; pk1 = pk2;
+      if (pk >= (int)p_end) break;
+      pk2 = first_valid(pk1 + 16);
+      if (pk2 < (int)p_end) fetch(pk2, ra2, rb2);
+      multiply(1);
+      if (pk1 < (int)p_end) store_tile(0, ra, rb);
+      __syncthreads();
+      pk = pk1; pk1 = pk2;
+    }
+  } else {
+    if (pk < (int)p_end) {
+      fetch(pk, ra, rb);
+      store_tile(0, ra, rb);
+    }
+    __syncthreads();
+    for (int it = 0; pk < (int)p_end; ++it) {
+      const int buf = it & 1;
+      const int pkn = first_valid(pk + 16);
+      const bool more = pkn < (int)p_end;
+      if (more) fetch(pkn, ra, rb);
+      pk = pkn;
+      multiply(buf);
+      if (more) store_tile(buf ^ 1, ra, rb);
+      __syncthreads();
+    }
   }
 
   // C/D map of the 16x16 MFMA (col = lane & 15, row = 4*(lane>>4) + reg) through the interleaving above:
@@ -550,8 +579,13 @@ int svs_wgrad_gemm_run(const float* s, long lds, int B, int Hs, int Ws, int Cs, 
   dim3 grid((unsigned)(Cs / pl.BM), (unsigned)((25 * Cl + pl.BN - 1) / pl.BN), (unsigned)pl.ksplit);
   const int skip = use_wgrad_skip(B, Hs, Ws, Cl, lds, pl.cfg);
   if (skip) a.b_shift = log2_or_neg(B);
+  // K-tiles requested ahead by the tap-skipping tiles: two (same-device A/B of tools/ab_tune.py WGRAD_PF 1 2 at batch 64: train step
+  // 3.465 -> 3.447 ms); WGRAD_PF = 1 / 2 for A/B runs
+  const int pf = svs_tune_on(SVS_TUNE_WGRAD_PF) ? (svs_tune(SVS_TUNE_WGRAD_PF) == 2 ? 2 : 1) : 2;
 #define SVS_WGRAD_LAUNCH(SPLIT_) \
-  if (skip) { \
+  if (skip && pf == 2 && pl.cfg == 0) hipLaunchKernelGGL((wgrad_gemm_kernel<128, 128, 2, 2, true, SPLIT_, 2>), grid, dim3(256), 0, stream, a); \
+  else if (skip && pf == 2 && pl.cfg == 1) hipLaunchKernelGGL((wgrad_gemm_kernel<64, 128, 1, 4, true, SPLIT_, 2>), grid, dim3(256), 0, stream, a); \
+  else if (skip) { \
     if (pl.cfg == 0) hipLaunchKernelGGL((wgrad_gemm_kernel<128, 128, 2, 2, true, SPLIT_>), grid, dim3(256), 0, stream, a); \
     else if (pl.cfg == 1) hipLaunchKernelGGL((wgrad_gemm_kernel<64, 128, 1, 4, true, SPLIT_>), grid, dim3(256), 0, stream, a); \
     else hipLaunchKernelGGL((wgrad_gemm_kernel<32, 128, 1, 4, true, SPLIT_>), grid, dim3(256), 0, stream, a); \
