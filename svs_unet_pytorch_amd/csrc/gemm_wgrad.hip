@@ -581,7 +581,8 @@ int svs_wgrad_gemm_run(const float* s, long lds, int B, int Hs, int Ws, int Cs, 
   if (skip) a.b_shift = log2_or_neg(B);
   // K-tiles requested ahead by the tap-skipping tiles: two (same-device A/B of tools/ab_tune.py WGRAD_PF 1 2 at batch 64: train step
   // 3.465 -> 3.447 ms); WGRAD_PF = 1 / 2 for A/B runs
-  const int pf = svs_tune_on(SVS_TUNE_WGRAD_PF) ? (svs_tune(SVS_TUNE_WGRAD_PF) == 2 ? 2 : 1) : 2;
+  int pf = 2;
+  if (svs_tune_on(SVS_TUNE_WGRAD_PF)) { const long f = svs_tune(SVS_TUNE_WGRAD_PF); pf = (f == 2 || (f == 3 && pl.cfg == 0) || (f == 4 && pl.cfg == 1)) ? 2 : 1; }   // 3 / 4: one tile shape only
 #define SVS_WGRAD_LAUNCH(SPLIT_) \
   if (skip && pf == 2 && pl.cfg == 0) hipLaunchKernelGGL((wgrad_gemm_kernel<128, 128, 2, 2, true, SPLIT_, 2>), grid, dim3(256), 0, stream, a); \
   else if (skip && pf == 2 && pl.cfg == 1) hipLaunchKernelGGL((wgrad_gemm_kernel<64, 128, 1, 4, true, SPLIT_, 2>), grid, dim3(256), 0, stream, a); \
