@@ -310,8 +310,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs p, std::con
   int kt_cur = first_valid(kt_begin);
   if constexpr (PF == 2) {
     // Two K-tiles in flight: the request for tile n + 2 goes out when tile n starts, so an operand has two tile times to arrive
-    // before it is written to LDS.  For launches with few resident waves per CU (small batches: every block of a deep layer is a
-    // chain of 25-100 short K-tiles) one tile time -- 512 MFMA cycles -- is less than an L2 / Infinity-Cache round trip.
+    // before it is written to LDS: one tile time -- 512 MFMA cycles on the 64x64 tile -- is less than an L2 / Infinity-Cache
+    // round trip under load (per layer at batch 64, one against two tiles ahead: deconv3 forward 130.7 -> 115.2 us, conv4
+    // backward-data 70.1 -> 63.3, the deep layers -1 ... -5 %).  Written out as two phases so that register set and LDS buffer are
+    // compile-time choices.  THREE tiles ahead (six phases) and a generic ring of PF sets with computed indices both measured
+    // ~5 % SLOWER on the whole train step (3.60 / 3.63 against 3.43 / 3.445 ms, same device): the loop body triples.
     int kt_n1 = first_valid(kt_cur + 1);
     if (kt_cur < kt_end) load_tile_to(kt_cur, ra, rb);
     if (kt_n1 < kt_end) load_tile_to(kt_n1, ra2, rb2);
