@@ -42,7 +42,8 @@ __global__ __launch_bounds__(256) void channel_reduce_kernel(BnCtx p, float* __r
     beta4 = *(const f32x4*)(p.beta + cg * 4);
   }
   if (pl < PL) {
-    for (long pix = p0 + pl; pix < p1; pix += PL) {
+#pragma unroll 4
+    for (long pix = p0 + pl; pix < p1; pix += PL) {        // (unrolled: four pixels' loads in flight per thread)
       const f32x4 x = *(const f32x4*)(p.raw + pix * p.ldr + cg * 4);
       if (MODE == 0) {
         s0 += x;
@@ -124,6 +125,7 @@ __global__ __launch_bounds__(256) void bn_act_apply_kernel(BnCtx p, float* __res
   const unsigned G = (unsigned)p.C >> 2;
   const unsigned total = (unsigned)(p.P * G);
   const unsigned pps = (unsigned)p.pps;
+#pragma unroll 4
   for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
     unsigned cg, pixu;
     if (g_shift >= 0) { cg = i & (G - 1); pixu = i >> g_shift; }
@@ -175,6 +177,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnCtx p, const float*
   const f32x4 c1 = *(const f32x4*)(coef + p.C + cg * 4);
   const f32x4 c2 = *(const f32x4*)(coef + 2 * p.C + cg * 4);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
   for (long pix = p0 + pl; pix < p1; pix += PL) {
     const f32x4 x = *(const f32x4*)(p.raw + pix * p.ldr + cg * 4);
     f32x4 dz = *(const f32x4*)(p.dy + pix * p.lddy + cg * 4);
