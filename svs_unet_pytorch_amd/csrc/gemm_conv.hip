@@ -1331,8 +1331,10 @@ int svs_conv_gemm_describe(int mode, int B, int H, int W, int C, int Ho, int Wo,
   static const int wm[10] = {2, 2, 4, 4, 1, 2, 2, 4, 4, 4}, wn[10] = {2, 2, 1, 1, 4, 2, 2, 1, 1, 1};     // (6 = 64x128, 2x2 waves)
   const ConvPlan pl = plan_conv(mode, Mmax, N, nkt_min, narrow_level(mode, B, C, Wo, N));
   const bool skip = use_tap_skip(mode, B, C, Wo, N, pl.cfg) != 0;
-  snprintf(buf, n, "conv_gemm_kernel<%d, %d, %d, %d, %d, %s, %s>", mode, pl.BM, pl.BN, wm[pl.cfg], wn[pl.cfg],
-           skip ? "true" : "false", svs_tune(SVS_TUNE_MFMA_SPLIT) > 0 ? "true" : "false");
+  // (the last template argument, K-tiles requested ahead, exists as 2 only for the tile shapes launch_conv_gemm_cfg has it for)
+  const int pf = (pl.pf == 2 && (pl.cfg == 5 || pl.cfg == 6 || pl.cfg == 1 || (!skip && (pl.cfg == 2 || pl.cfg == 3)))) ? 2 : 1;
+  snprintf(buf, n, "conv_gemm_kernel<%d, %d, %d, %d, %d, %s, %s, %d>", mode, pl.BM, pl.BN, wm[pl.cfg], wn[pl.cfg],
+           skip ? "true" : "false", svs_tune(SVS_TUNE_MFMA_SPLIT) > 0 ? "true" : "false", pf);
   ConvBal show{};
   const int sb = skip ? plan_balance(mode, B, H, W, C, Ho, Wo, N, pl, svs_tune(SVS_TUNE_CONV_BALANCE) == 2 ? &show : nullptr) : 0;      // balanced: the largest split count
   return sb ? sb : pl.ksplit;

@@ -606,7 +606,11 @@ int svs_wgrad_gemm_describe(int B, int Hs, int Ws, int Cs, int Cl, char* buf, si
   const WgWinPlan wp = plan_wgrad_window(B, Hs, Ws, Cs, Cl);
   if (wp.use) { snprintf(buf, n, "wgrad_window_kernel<%d>", wp.MT); return wp.nslab; }
   const WgradPlan pl = plan_wgrad(B, Hs, Ws, Cs, Cl);
-  snprintf(buf, n, "wgrad_gemm_kernel<%d, %d, %d, %d, %s, %s>", pl.BM, pl.BN, pl.cfg == 0 ? 2 : 1, pl.cfg == 0 ? 2 : 4,
-           use_wgrad_skip(B, Hs, Ws, Cl, Cs, pl.cfg) ? "true" : "false", svs_tune(SVS_TUNE_MFMA_SPLIT) > 0 ? "true" : "false");
+  const bool skip = use_wgrad_skip(B, Hs, Ws, Cl, Cs, pl.cfg) != 0;
+  int pf = 2;
+  if (svs_tune_on(SVS_TUNE_WGRAD_PF)) { const long f = svs_tune(SVS_TUNE_WGRAD_PF); pf = (f == 2 || (f == 3 && pl.cfg == 0) || (f == 4 && pl.cfg == 1)) ? 2 : 1; }
+  if (!skip || pl.cfg > 1) pf = 1;           // (the two-ahead variant exists for the tap-skipping 128x128 and 64x128 tiles)
+  snprintf(buf, n, "wgrad_gemm_kernel<%d, %d, %d, %d, %s, %s, %d>", pl.BM, pl.BN, pl.cfg == 0 ? 2 : 1, pl.cfg == 0 ? 2 : 4,
+           skip ? "true" : "false", svs_tune(SVS_TUNE_MFMA_SPLIT) > 0 ? "true" : "false", pf);
   return pl.ksplit;
 }
