@@ -253,9 +253,9 @@ def test_production_kernels_at_batch_32(report, tune):
     L.svs_describe_plan(1, B, 128, 32, 64, 256, 64, 16, buf, 128)            # deconv5 forward
     assert buf.value.decode().startswith("parity_window_kernel"), buf.value
     L.svs_describe_plan(0, B, 16, 4, 256, 8, 2, 512, buf, 128)               # conv6 forward
-    assert buf.value.decode().split(", ")[-2] == "true", buf.value           # <..., tap skipping, split-bf16 products>
+    assert buf.value.decode().split(", ")[-3] == "true", buf.value           # <..., tap skipping, split-bf16 products, K-tiles ahead>
     L.svs_describe_plan(2, B, 8, 2, 512, 0, 0, 256, buf, 128)                # conv6 weight gradient
-    assert buf.value.decode().split(", ")[-2] == "true", buf.value
+    assert buf.value.decode().split(", ")[-3] == "true", buf.value
 
     def run():
         m = make_model(trained_stats=False).train()
@@ -269,7 +269,7 @@ def test_production_kernels_at_batch_32(report, tune):
     for k, v in (("CONV_SKIP", 0), ("WGRAD_SKIP", 0), ("CONV_WINDOW", 0), ("TRAIN_ONE_STREAM", 1), ("TRAIN_UNFUSED", 1)):
         tune(k, v)
     L.svs_describe_plan(0, B, 16, 4, 256, 8, 2, 512, buf, 128)
-    assert buf.value.decode().split(", ")[-2] == "false", buf.value
+    assert buf.value.decode().split(", ")[-3] == "false", buf.value
     loss_plain, g_plain, bn_plain, named_plain = run()
     assert report("B32 loss: production vs plain kernels", abs(loss_fast - loss_plain) / loss_plain, 1e-6)
     assert report("B32 BatchNorm buffers: production vs plain kernels", relerr(bn_fast, bn_plain), 1e-6)
