@@ -147,7 +147,13 @@ __global__ __launch_bounds__(256, COUT == 32 ? 3 : 2) void conv_c1_tiled_kernel(
       for (int kh = 0; kh < 5; ++kh) {
         const float2* row = (const float2*)(&win[(2 * lr + kh) * WWD + 2 * lc]);
         const float2 a = row[0], c = row[1], e = row[2];
-        acc += wr[kh * 5 + 0] * a.x; acc += wr[kh * 5 + 1] * a.y; acc += wr[kh * 5 + 2] * c.x; acc += wr[kh * 5 + 3] * c.y;
+        // the odd samples sit in the HIGH half of their loaded register pair; multiplied as they stand, the packed FMA takes
+        // them with op_sel:[1,..] -- the form that returns garbage beside a bf16 MFMA on gfx950 (tools/check_isa.py, DESIGN
+        // section 5).  A copy into a register of its own makes it a plain low-half broadcast.
+        float ay = a.y, cy = c.y;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(ay) : "v"(a.y));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(cy) : "v"(c.y));
+        acc += wr[kh * 5 + 0] * a.x; acc += wr[kh * 5 + 1] * ay; acc += wr[kh * 5 + 2] * c.x; acc += wr[kh * 5 + 3] * cy;
         acc += wr[kh * 5 + 4] * e.x;
       }
       if (p.scale) {
