@@ -17,11 +17,12 @@
 //                   real part, y in the imaginary part); per-block partial sums of (|Y|-|X|)^2, |Y|^2, |log|X|-log|Y||.
 //   mr_finalize     fixed-order double-precision sums -> loss value, the log-magnitude gradient coefficient per resolution and
 //                   the spectral-convergence gradient coefficient per resolution and waveform.
-//   mr_grad_kernel  recomputes the spectra (cheaper than storing 12 bytes per bin), forms dL/dX, and brings TWO frames
-//                   back with one inverse FFT (Hermitian-extended spectra of frames t, t+1 in the real / imaginary part);
-//                   the windowed frame gradients go to a frame buffer.
-//   mr_ola_kernel   gathers, per output sample, the contributions of every frame (and of the two reflect-padding
-//                   mirrors) in a fixed order -- no atomics, bitwise reproducible.
+//   mr_pass_kernel  (when the gradient is wanted, instead of mr_sums) the same sums AND, from the same spectra, both unscaled
+//                   gradient parts of the frame brought back with ONE inverse FFT (real / imaginary part);
+//                   the 16 frames of a block are overlap-added in LDS (fixed order) and leave as ONE segment of
+//                   15 hop + win samples -- a quarter of the bytes of the 16 windowed frames (hop is win / 5).
+//   mr_ola_kernel   gathers, per output sample, the (at most two) segments that cover it, for the sample itself and for the
+//                   two reflect-padding mirrors, in a fixed order -- no atomics, bitwise reproducible.
 // Bound: HBM + VALU (FFT); algorithmic FLOPs ~ 2.5 * 5 N log2 N per frame position.
 #include "internal.h"
 #include "fft_wave.h"
@@ -47,7 +48,7 @@ struct MrArgs {
   int hop, win, F;                                   // this resolution: hop, window length, frames = 1 + L / hop
   float* partial;                                    // [B * gridDim.x][3]
   const float* coef;                                 // [1 + B]: log-magnitude coefficient, then the SC coefficient of every waveform (device)
-  float* frames;                                     // [B][F][win] windowed frame gradients (the window's support only)
+  float* frames;                                     // [B][ceil(F / 16)][15 hop + win]: the blocks' overlap-added frame gradients ("segments")
 };
 
 // periodic Hann window of `win` samples, centred inside n_fft (torch.stft pads a short window on both sides), sample j of the
@@ -162,86 +163,114 @@ __global__ __launch_bounds__(1024) void mr_finalize_kernel(MrFinalArgs a) {
   }
 }
 
+// ONE pass for the loss value AND the gradient (used whenever the gradient is asked for): a wave transforms frame t once (x real,
+// y imaginary), adds the frame's three partial sums, and forms BOTH gradient spectra from the same X, Y -- the
+// spectral-convergence part -(|Y| - |X|) X / |X| and the log-magnitude part sign(|X| - |Y|) X / |X|^2, each WITHOUT its global
+// coefficient (1 / (B ||Y_b| - |X_b|| ||Y_b||) is known only after all frames: mr_finalize) -- as the real and imaginary part of
+// one inverse transform.  Everything after the spectra is linear, so the coefficients are applied at the very end, in mr_ola.
+// Two transforms per frame; the two-pass form (sums, then spectra again for the gradient, two frames per inverse) needed 2.5.
+// The block's 8 frames are overlap-added in LDS (fixed order) and leave as ONE segment of 7 hop + win positions x (sc, log): a
+// third of the bytes of the windowed frames.
 template <int N>
-__global__ __launch_bounds__(64 * MrCfg<N>::WAVES) void mr_grad_kernel(MrArgs p) {
+__global__ __launch_bounds__(64 * MrCfg<N>::WAVES) void mr_pass_kernel(MrArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int BUF = FftSize<N>::BUF, NR = N / 128 + 1, WV = MrCfg<N>::WAVES;
+  constexpr int BUF = FftSize<N>::BUF, TW = FftSize<N>::TW, NR = N / 128 + 1, WV = MrCfg<N>::WAVES;
   float2* const fbuf = (float2*)smem;
   float2* const tw = fbuf + WV * BUF;
+  float* const red = (float*)(tw + TW);              // [WV][3]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.y, ta = blockIdx.x * (2 * WV) + 2 * wave;
+  const int b = blockIdx.y, t = blockIdx.x * WV + wave;
   fft_build_twiddles<N>(tw, tid, 64 * WV);
-  __syncthreads();
-  if (ta >= p.F) return;                             // (no barriers below: waves are independent)
   float2* const buf = fbuf + wave * BUF;
-  const float clog = p.coef[0], csc = p.coef[1 + b];
-  float2 H[2][NR];                                   // Hermitian-weighted dL/dX of frames ta, ta + 1
+  mr_fill<N>(buf, p, b, t, lane);                    // (zeros past the last frame)
+  __syncthreads();
+  fft_wave<N>(buf, tw, lane);
+  float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  float2 Hs[NR], Hl[NR];                             // Hermitian-weighted, unscaled dL/dX: spectral-convergence and log-magnitude parts
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    mr_fill<N>(buf, p, b, ta + h, lane);
-    fft_wave<N>(buf, tw, lane);
-#pragma unroll
-    for (int r = 0; r < NR; ++r) {
-      const int k = lane + 64 * r;
-      float2 g = float2{0.f, 0.f};
-      if (k <= N / 2 && ta + h < p.F) {
-        float2 X, Y;
-        mr_split(buf[fft_pad(k)], buf[fft_pad((N - k) & (N - 1))], X, Y);
-        const float x2 = X.x * X.x + X.y * X.y;
-        if (x2 > MR_EPS) {                           // clamp(min=eps) passes no gradient below eps
-          const float y2 = fmaxf(Y.x * Y.x + Y.y * Y.y, MR_EPS);
-          const float xm = __builtin_amdgcn_sqrtf(x2), ym = __builtin_amdgcn_sqrtf(y2), ix = __builtin_amdgcn_rcpf(xm);
-          // sign(log|X| - log|Y|) = sign(|X|^2 - |Y|^2)
-          const float gm = -csc * (ym - xm) + clog * (x2 > y2 ? 1.f : (x2 < y2 ? -1.f : 0.f)) * ix;   // dL/d|X|
-          const bool edge = (k == 0 || k == N / 2);
-          const float wgt = (edge ? 1.0f : 0.5f) * gm * ix;
-          g = float2{wgt * X.x, edge ? 0.f : wgt * X.y};
-        }
+  for (int r = 0; r < NR; ++r) {
+    const int k = lane + 64 * r;
+    Hs[r] = Hl[r] = float2{0.f, 0.f};
+    if (k <= N / 2 && t < p.F) {
+      float2 X, Y;
+      mr_split(buf[fft_pad(k)], buf[fft_pad((N - k) & (N - 1))], X, Y);
+      const float x2r = X.x * X.x + X.y * X.y;
+      const float x2 = fmaxf(x2r, MR_EPS), y2 = fmaxf(Y.x * Y.x + Y.y * Y.y, MR_EPS);
+      const float xm = __builtin_amdgcn_sqrtf(x2), ym = __builtin_amdgcn_sqrtf(y2);
+      const float d = ym - xm;
+      s1 += d * d;
+      s2 += y2;
+      s3 += 0.34657359027997264f * fabsf(__builtin_amdgcn_logf(x2) - __builtin_amdgcn_logf(y2));
+      if (x2r > MR_EPS) {                            // clamp(min=eps) passes no gradient below eps
+        const float ix = __builtin_amdgcn_rcpf(xm);
+        const bool edge = (k == 0 || k == N / 2);
+        const float h = (edge ? 1.0f : 0.5f) * ix;
+        const float gs = -d * h, gl = (x2 > y2 ? 1.f : (x2 < y2 ? -1.f : 0.f)) * ix * h;      // sign(log|X| - log|Y|) = sign(|X|^2 - |Y|^2)
+        Hs[r] = float2{gs * X.x, edge ? 0.f : gs * X.y};
+        Hl[r] = float2{gl * X.x, edge ? 0.f : gl * X.y};
       }
-      H[h][r] = g;
     }
-    fft_wave_sync();                                 // every lane has read this frame's spectra before the buffer is refilled
   }
-  // conj(Z), Z = Ha + i Hb extended Hermitian; forward transform -> conj(ifft(Z)) = ga - i gb
+  fft_wave_sync();                                   // every lane has read the spectra before the buffer is refilled
+  // conj(Z), Z = Hs + i Hl extended Hermitian; forward transform -> conj(ifft(Z)) = g_sc - i g_log
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
     const int k = lane + 64 * r;
     if (k > N / 2) continue;
-    const float2 a = H[0][r], c = H[1][r];
+    const float2 a = Hs[r], c = Hl[r];
     buf[fft_pad(k)] = float2{a.x - c.y, -(a.y + c.x)};
     if (k > 0 && k < N / 2) buf[fft_pad(N - k)] = float2{a.x + c.y, -(c.x - a.y)};
   }
   fft_wave<N>(buf, tw, lane);
+  s1 = svs_wave_sum(s1); s2 = svs_wave_sum(s2); s3 = svs_wave_sum(s3);
+  if (lane == 0) { red[wave * 3] = s1; red[wave * 3 + 1] = s2; red[wave * 3 + 2] = s3; }
+  __syncthreads();
+  if (tid < 3) {
+    float a = 0.f;
+    for (int w = 0; w < WV; ++w) a += red[w * 3 + tid];
+    p.partial[((long)b * gridDim.x + blockIdx.x) * 3 + tid] = a;
+  }
+  // ---- overlap-add of the block's WV frames (local frame f = its wave) over their common support: local position i = f hop + j,
+  // j = index inside the window.  A thread owns positions tid, tid + 64 WV, ... and adds the <= ceil(win / hop) frames that
+  // cover each in ascending f: a fixed order.
   constexpr int WIN = MrCfg<N>::WIN, off = MrCfg<N>::OFF;
-  float* const fa = p.frames + ((long)b * p.F + ta) * WIN;
+  const int t0 = blockIdx.x * WV, SL = (WV - 1) * p.hop + WIN;
+  float2* const seg = (float2*)p.frames + ((long)b * gridDim.x + blockIdx.x) * SL;
   const float inv_win = 1.0f / (float)WIN;
-  const bool second = ta + 1 < p.F;
-#pragma unroll 5
-  for (int r = 0; r < MrCfg<N>::NJ; ++r) {           // the window is zero outside its support: only `win` of the N samples exist
-    const int j = lane + 64 * r;
-    if (j >= WIN) break;
-    const float2 z = buf[fft_pad(j + off)];
-    const float w = mr_window_at(j, inv_win);
-    fa[j] = z.x * w;
-    if (second) fa[WIN + j] = -z.y * w;
+  for (int i = tid; i < SL; i += 64 * WV) {
+    int f_hi = (int)((unsigned)i / (unsigned)p.hop);
+    if (f_hi > WV - 1) f_hi = WV - 1;
+    if (t0 + f_hi > p.F - 1) f_hi = p.F - 1 - t0;
+    int f_lo = i - (WIN - 1);
+    f_lo = f_lo <= 0 ? 0 : (int)((unsigned)(f_lo + p.hop - 1) / (unsigned)p.hop);
+    float2 s = float2{0.f, 0.f};
+    for (int f = f_lo; f <= f_hi; ++f) {
+      const int j = i - f * p.hop;
+      const float2 z = fbuf[f * BUF + fft_pad(j + off)];
+      const float w = mr_window_at(j, inv_win);
+      s.x += z.x * w;
+      s.y -= z.y * w;
+    }
+    seg[i] = s;
   }
 }
 
 struct MrOlaArgs {
-  const float* frames[MR_NRES]; int n[MR_NRES], hop[MR_NRES], F[MR_NRES], win[MR_NRES];
+  const float* frames[MR_NRES]; const float* coef[MR_NRES]; int n[MR_NRES], hop[MR_NRES], F[MR_NRES], win[MR_NRES];
   int B; long L; float* d_x;
 };
-// contributions of padded position q (= p + N/2) of one resolution to its sample: every frame t whose window support
-// covers it, hop t + off <= q < hop t + off + win (off = (N - win) / 2), in ascending t -- a fixed order
-__device__ __forceinline__ float mr_gather(const float* fr, int N, int win, int hop, int F, int q) {
-  const int qq = q - (N - win) / 2;                       // (32-bit throughout: L + n_fft < 2^31 is checked on the host; a 64-bit
-  if (qq < 0) return 0.f;                                 //  division costs ~100 instructions and there were 18 per sample)
-  int t1 = (int)((unsigned)qq / (unsigned)hop);
-  if (t1 > F - 1) t1 = F - 1;
-  int t0 = qq - (win - 1);
-  t0 = t0 <= 0 ? 0 : (int)((unsigned)(t0 + hop - 1) / (unsigned)hop);
-  float s = 0.f;
-  for (int t = t0; t <= t1; ++t) s += fr[(long)t * win + (qq - t * hop)];
+// contributions of padded position q (= p + N/2) of one resolution to its sample: in "frame-window" coordinates u = q - off
+// (= hop t + j for a frame t and a window index j) the sample takes the block segments that cover u -- segment k spans
+// [8 hop k, 8 hop k + 7 hop + win) -- at most two of them, the earlier block first: a fixed order.  (sc, log) pairs.
+__device__ __forceinline__ float2 mr_gather(const float2* sg, int N, int win, int hop, int nseg, int q) {
+  const int u = q - (N - win) / 2;                        // (32-bit throughout: L + n_fft < 2^31 is checked on the host)
+  float2 s = float2{0.f, 0.f};
+  if (u < 0) return s;
+  const int span = 8 * hop, SL = 7 * hop + win;
+  const int k = (int)((unsigned)u / (unsigned)span);
+  const int r = u - k * span;                             // position inside segment k
+  if (k >= 1 && k - 1 < nseg && r + span < SL) { const float2 v = sg[(long)(k - 1) * SL + r + span]; s.x += v.x; s.y += v.y; }   // the previous segment's tail
+  if (k < nseg && r < SL) { const float2 v = sg[(long)k * SL + r]; s.x += v.x; s.y += v.y; }
   return s;
 }
 __global__ __launch_bounds__(256) void mr_ola_kernel(MrOlaArgs a) {
@@ -253,11 +282,13 @@ __global__ __launch_bounds__(256) void mr_ola_kernel(MrOlaArgs a) {
 #pragma unroll
     for (int r = 0; r < MR_NRES; ++r) {
       const int N = a.n[r], half = N / 2;
-      const float* fr = a.frames[r] + (long)b * a.F[r] * a.win[r];
-      s += mr_gather(fr, N, a.win[r], a.hop[r], a.F[r], nidx + half);                                 // the sample itself
-      if (nidx >= 1 && nidx <= half) s += mr_gather(fr, N, a.win[r], a.hop[r], a.F[r], half - nidx);  // left mirror: p = -n
-      const int pr = 2 * (L - 1) - nidx;                                                               // right mirror: p = 2(L-1) - n
-      if (nidx <= L - 2 && pr < L + half) s += mr_gather(fr, N, a.win[r], a.hop[r], a.F[r], pr + half);
+      const int nseg = (a.F[r] + 7) / 8;
+      const float2* fr = (const float2*)a.frames[r] + (long)b * nseg * (7 * a.hop[r] + a.win[r]);
+      float2 g = mr_gather(fr, N, a.win[r], a.hop[r], nseg, nidx + half);                                  // the sample itself
+      if (nidx >= 1 && nidx <= half) { const float2 v = mr_gather(fr, N, a.win[r], a.hop[r], nseg, half - nidx); g.x += v.x; g.y += v.y; }   // left mirror: p = -n
+      const int pr = 2 * (L - 1) - nidx;                                                                    // right mirror: p = 2(L-1) - n
+      if (nidx <= L - 2 && pr < L + half) { const float2 v = mr_gather(fr, N, a.win[r], a.hop[r], nseg, pr + half); g.x += v.x; g.y += v.y; }
+      s += a.coef[r][1 + b] * g.x + a.coef[r][0] * g.y;         // the global coefficients of mr_finalize: spectral convergence (per waveform), log magnitude
     }
     a.d_x[(long)b * L + nidx] = s;
   }
@@ -276,7 +307,7 @@ static MrWs mr_layout(int B, long L, void* ws) {
     const int F = (int)(1 + L / MR_HOP[r]);
     w.nblk[r] = B * ((F + mr_waves(MR_NFFT[r]) - 1) / mr_waves(MR_NFFT[r]));
     w.partial[r] = take((size_t)w.nblk[r] * 3);
-    w.frames[r] = take((size_t)B * F * MR_WIN[r]);
+    w.frames[r] = take((size_t)2 * B * ((F + 7) / 8) * (7 * MR_HOP[r] + MR_WIN[r]));     // one overlap-added (sc, log) segment per block of 8 frames
   }
   w.total = used;
   return w;
@@ -284,18 +315,18 @@ static MrWs mr_layout(int B, long L, void* ws) {
 extern "C" size_t svs_mrstft_workspace_bytes(int B, int64_t L) { return B > 0 && L > 0 ? mr_layout(B, L, nullptr).total : 0; }
 
 template <int N>
-static int mr_launch(bool grad, const MrArgs& a, int B, hipStream_t stream) {
+static int mr_launch(bool grad, const MrArgs& a, int B, hipStream_t stream) {      // grad: the one-pass kernel (sums + gradient segments), else the sums only
   const size_t lds = mr_lds_bytes<N>();
+  constexpr int per = MrCfg<N>::WAVES;
+  const dim3 grid((unsigned)((a.F + per - 1) / per), (unsigned)B), block(64 * MrCfg<N>::WAVES);
   if (grad) {
-    SVS_HIP(hipFuncSetAttribute((const void*)mr_grad_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    constexpr int per = 2 * MrCfg<N>::WAVES;
-    hipLaunchKernelGGL(mr_grad_kernel<N>, dim3((unsigned)((a.F + per - 1) / per), (unsigned)B), dim3(64 * MrCfg<N>::WAVES), lds, stream, a);
+    SVS_HIP(hipFuncSetAttribute((const void*)mr_pass_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(mr_pass_kernel<N>, grid, block, lds, stream, a);
   } else {
     SVS_HIP(hipFuncSetAttribute((const void*)mr_sums_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    constexpr int per = MrCfg<N>::WAVES;
-    hipLaunchKernelGGL(mr_sums_kernel<N>, dim3((unsigned)((a.F + per - 1) / per), (unsigned)B), dim3(64 * MrCfg<N>::WAVES), lds, stream, a);
+    hipLaunchKernelGGL(mr_sums_kernel<N>, grid, block, lds, stream, a);
   }
-  SVS_CHECK_LAUNCH(grad ? "mr_grad" : "mr_sums");
+  SVS_CHECK_LAUNCH(grad ? "mr_pass" : "mr_sums");
   return SVS_OK;
 }
 
@@ -309,25 +340,21 @@ extern "C" int svs_mrstft_loss_fwd_bwd(const float* x, const float* y, int B, in
   int rc;
   MrArgs a[MR_NRES];
   MrFinalArgs f{};
+  const bool grad = d_x != nullptr;
+  MrOlaArgs o{};
   for (int r = 0; r < MR_NRES; ++r) {
     a[r] = MrArgs{x, y, B, (long)L, MR_HOP[r], MR_WIN[r], (int)(1 + L / MR_HOP[r]), w.partial[r], w.coef + (size_t)r * (1 + B), w.frames[r]};
-    rc = MR_NFFT[r] == 1024 ? mr_launch<1024>(false, a[r], B, stream) : MR_NFFT[r] == 2048 ? mr_launch<2048>(false, a[r], B, stream)
-                                                                                              : mr_launch<512>(false, a[r], B, stream);
+    rc = MR_NFFT[r] == 1024 ? mr_launch<1024>(grad, a[r], B, stream) : MR_NFFT[r] == 2048 ? mr_launch<2048>(grad, a[r], B, stream)
+                                                                                             : mr_launch<512>(grad, a[r], B, stream);
     if (rc) return rc;
     f.partial[r] = w.partial[r]; f.gx[r] = w.nblk[r] / B; f.coef[r] = w.coef + (size_t)r * (1 + B);
     f.count[r] = (double)B * a[r].F * (MR_NFFT[r] / 2 + 1);
+    o.frames[r] = w.frames[r]; o.coef[r] = f.coef[r]; o.n[r] = MR_NFFT[r]; o.hop[r] = MR_HOP[r]; o.F[r] = a[r].F; o.win[r] = MR_WIN[r];
   }
   f.B = B; f.grad_scale = grad_scale; f.loss = loss;
   hipLaunchKernelGGL(mr_finalize_kernel, dim3(1), dim3(1024), 0, stream, f);
   SVS_CHECK_LAUNCH("mr_finalize");
-  if (!d_x) return SVS_OK;
-  MrOlaArgs o{};
-  for (int r = 0; r < MR_NRES; ++r) {
-    rc = MR_NFFT[r] == 1024 ? mr_launch<1024>(true, a[r], B, stream) : MR_NFFT[r] == 2048 ? mr_launch<2048>(true, a[r], B, stream)
-                                                                                             : mr_launch<512>(true, a[r], B, stream);
-    if (rc) return rc;
-    o.frames[r] = w.frames[r]; o.n[r] = MR_NFFT[r]; o.hop[r] = MR_HOP[r]; o.F[r] = a[r].F; o.win[r] = MR_WIN[r];
-  }
+  if (!grad) return SVS_OK;
   o.B = B; o.L = L; o.d_x = d_x;
   long g = (L + 255) / 256;
   if (g > 1024) g = 1024;
