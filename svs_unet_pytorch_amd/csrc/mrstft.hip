@@ -123,45 +123,47 @@ __global__ __launch_bounds__(64 * MrCfg<N>::WAVES) void mr_sums_kernel(MrArgs p)
 
 struct MrFinalArgs {
   const float* partial[MR_NRES]; int gx[MR_NRES]; double count[MR_NRES];        // partial[r]: [B][gx[r]][3]
-  int B; float grad_scale; float* loss; float* coef[MR_NRES];                   // coef[r]: [1 + B]
+  int B; float grad_scale; double* terms; float* coef[MR_NRES];                 // terms: [MR_NRES] this resolution's loss; coef[r]: [1 + B]
 };
-// One wave per waveform (16 waves walk b = wave, wave + 16, ...): the lanes sum that waveform's gx block partials, lane 0 forms
-// its spectral-convergence ratio and gradient coefficient and keeps the wave's running sums; thread 0 adds the 16 waves'
-// sums in a fixed order.  Everything in double, every order fixed: bitwise reproducible.
+// One block per resolution, one wave per waveform (16 waves walk b = wave, wave + 16, ...): the lanes sum that waveform's gx
+// block partials, lane 0 forms its spectral-convergence ratio and gradient coefficient and keeps the wave's running sums;
+// thread 0 adds the 16 waves' sums in a fixed order.  Everything in double, every order fixed: bitwise reproducible.  (One
+// block for all three resolutions took 28 us -- twelve dependent (resolution, waveform) rounds per wave; the three terms are
+// added by whoever runs next: mr_ola, or mr_total for a value-only call.)
 __global__ __launch_bounds__(1024) void mr_finalize_kernel(MrFinalArgs a) {
-  __shared__ double sh[MR_NRES][2][16];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int r = 0; r < MR_NRES; ++r) {
-    double ratio_sum = 0.0, log_sum = 0.0;
-    for (int b = wave; b < a.B; b += 16) {
-      double s[3] = {0.0, 0.0, 0.0};
-      const float* pb = a.partial[r] + (long)b * a.gx[r] * 3;
-      for (int i = lane; i < a.gx[r]; i += 64)
-        for (int j = 0; j < 3; ++j) s[j] += (double)pb[(long)i * 3 + j];
-      for (int j = 0; j < 3; ++j)
-        for (int o = 32; o > 0; o >>= 1) s[j] += __shfl_xor(s[j], o, 64);
-      if (lane == 0) {
-        const double nd = sqrt(s[0]), ny = sqrt(s[1]);
-        ratio_sum += ny > 0.0 ? nd / ny : 0.0;
-        log_sum += s[2];
-        // d/d|X_b| of  (1/B) ||Y_b|-|X_b||_F / ||Y_b||_F  is  -(|Y_b|-|X_b|) / (B ||Y_b|-|X_b||_F ||Y_b||_F)
-        a.coef[r][1 + b] = (nd > 0.0 && ny > 0.0) ? (float)((double)a.grad_scale / (MR_NRES * (double)a.B * nd * ny)) : 0.f;
-      }
+  __shared__ double sh[2][16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = blockIdx.x;
+  double ratio_sum = 0.0, log_sum = 0.0;
+  for (int b = wave; b < a.B; b += 16) {
+    double s[3] = {0.0, 0.0, 0.0};
+    const float* pb = a.partial[r] + (long)b * a.gx[r] * 3;
+    for (int i = lane; i < a.gx[r]; i += 64)
+      for (int j = 0; j < 3; ++j) s[j] += (double)pb[(long)i * 3 + j];
+    for (int j = 0; j < 3; ++j)
+      for (int o = 32; o > 0; o >>= 1) s[j] += __shfl_xor(s[j], o, 64);
+    if (lane == 0) {
+      const double nd = sqrt(s[0]), ny = sqrt(s[1]);
+      ratio_sum += ny > 0.0 ? nd / ny : 0.0;
+      log_sum += s[2];
+      // d/d|X_b| of  (1/B) ||Y_b|-|X_b||_F / ||Y_b||_F  is  -(|Y_b|-|X_b|) / (B ||Y_b|-|X_b||_F ||Y_b||_F)
+      a.coef[r][1 + b] = (nd > 0.0 && ny > 0.0) ? (float)((double)a.grad_scale / (MR_NRES * (double)a.B * nd * ny)) : 0.f;
     }
-    if (lane == 0) { sh[r][0][wave] = ratio_sum; sh[r][1][wave] = log_sum; }
   }
+  if (lane == 0) { sh[0][wave] = ratio_sum; sh[1][wave] = log_sum; }
   __syncthreads();
   if (tid == 0) {
-    double total = 0.0;
-    for (int r = 0; r < MR_NRES; ++r) {
-      double ratio = 0.0, lg = 0.0;
-      for (int w = 0; w < 16; ++w) { ratio += sh[r][0][w]; lg += sh[r][1][w]; }
-      total += ratio / (double)a.B + lg / a.count[r];
-      a.coef[r][0] = (float)((double)a.grad_scale / (MR_NRES * a.count[r]));      // of the mean log distance: sign / (count |X|)
-    }
-    a.loss[0] = (float)(total / MR_NRES);
+    double ratio = 0.0, lg = 0.0;
+    for (int w = 0; w < 16; ++w) { ratio += sh[0][w]; lg += sh[1][w]; }
+    a.terms[r] = ratio / (double)a.B + lg / a.count[r];
+    a.coef[r][0] = (float)((double)a.grad_scale / (MR_NRES * a.count[r]));      // of the mean log distance: sign / (count |X|)
   }
 }
+__device__ __forceinline__ float mr_total(const double* terms) {              // mean over the resolutions, in their fixed order
+  double t = 0.0;
+  for (int r = 0; r < MR_NRES; ++r) t += terms[r];
+  return (float)(t / MR_NRES);
+}
+__global__ void mr_total_kernel(const double* terms, float* loss) { loss[0] = mr_total(terms); }
 
 // ONE pass for the loss value AND the gradient (used whenever the gradient is asked for): a wave transforms frame t once (x real,
 // y imaginary), adds the frame's three partial sums, and forms BOTH gradient spectra from the same X, Y -- the
@@ -257,7 +259,7 @@ __global__ __launch_bounds__(64 * MrCfg<N>::WAVES) void mr_pass_kernel(MrArgs p)
 
 struct MrOlaArgs {
   const float* frames[MR_NRES]; const float* coef[MR_NRES]; int n[MR_NRES], hop[MR_NRES], F[MR_NRES], win[MR_NRES];
-  int B; long L; float* d_x;
+  int B; long L; float* d_x; const double* terms; float* loss;
 };
 // contributions of padded position q (= p + N/2) of one resolution to its sample: in "frame-window" coordinates u = q - off
 // (= hop t + j for a frame t and a window index j) the sample takes the block segments that cover u -- segment k spans
@@ -277,6 +279,7 @@ __global__ __launch_bounds__(256) void mr_ola_kernel(MrOlaArgs a) {
   const int L = (int)a.L;
   // one waveform per blockIdx.y: no division by L per sample
   const int b = blockIdx.y;
+  if (blockIdx.x == 0 && b == 0 && threadIdx.x == 0) a.loss[0] = mr_total(a.terms);
   for (int nidx = blockIdx.x * 256 + threadIdx.x; nidx < L; nidx += gridDim.x * 256) {
     float s = 0.f;
 #pragma unroll
@@ -296,13 +299,14 @@ __global__ __launch_bounds__(256) void mr_ola_kernel(MrOlaArgs a) {
 
 // ---- host side -----------------------------------------------------------------------------------
 template <int N> static size_t mr_lds_bytes() { return (size_t)MrCfg<N>::WAVES * FftSize<N>::BUF * 8 + FftSize<N>::TW * 8 + 8 * 3 * 4 + 32; }
-struct MrWs { float* partial[MR_NRES]; int nblk[MR_NRES]; float* frames[MR_NRES]; float* coef; size_t total; };
+struct MrWs { float* partial[MR_NRES]; int nblk[MR_NRES]; float* frames[MR_NRES]; float* coef; double* terms; size_t total; };
 static MrWs mr_layout(int B, long L, void* ws) {
   MrWs w{};
   char* base = (char*)ws;
   size_t used = 0;
   auto take = [&](size_t nfloats) { float* p = base ? (float*)(base + used) : nullptr; used += svs_align_up(nfloats * 4, 256); return p; };
   w.coef = take((size_t)MR_NRES * (1 + B));
+  w.terms = (double*)take(2 * MR_NRES);
   for (int r = 0; r < MR_NRES; ++r) {
     const int F = (int)(1 + L / MR_HOP[r]);
     w.nblk[r] = B * ((F + mr_waves(MR_NFFT[r]) - 1) / mr_waves(MR_NFFT[r]));
@@ -351,11 +355,15 @@ extern "C" int svs_mrstft_loss_fwd_bwd(const float* x, const float* y, int B, in
     f.count[r] = (double)B * a[r].F * (MR_NFFT[r] / 2 + 1);
     o.frames[r] = w.frames[r]; o.coef[r] = f.coef[r]; o.n[r] = MR_NFFT[r]; o.hop[r] = MR_HOP[r]; o.F[r] = a[r].F; o.win[r] = MR_WIN[r];
   }
-  f.B = B; f.grad_scale = grad_scale; f.loss = loss;
-  hipLaunchKernelGGL(mr_finalize_kernel, dim3(1), dim3(1024), 0, stream, f);
+  f.B = B; f.grad_scale = grad_scale; f.terms = w.terms;
+  hipLaunchKernelGGL(mr_finalize_kernel, dim3(MR_NRES), dim3(1024), 0, stream, f);
   SVS_CHECK_LAUNCH("mr_finalize");
-  if (!grad) return SVS_OK;
-  o.B = B; o.L = L; o.d_x = d_x;
+  if (!grad) {
+    hipLaunchKernelGGL(mr_total_kernel, dim3(1), dim3(1), 0, stream, (const double*)w.terms, loss);
+    SVS_CHECK_LAUNCH("mr_total");
+    return SVS_OK;
+  }
+  o.B = B; o.L = L; o.d_x = d_x; o.terms = w.terms; o.loss = loss;
   long g = (L + 255) / 256;
   if (g > 1024) g = 1024;
   hipLaunchKernelGGL(mr_ola_kernel, dim3((unsigned)g, (unsigned)B), dim3(256), 0, stream, o);
