@@ -8,67 +8,90 @@
 // per-channel block reduction shared by bn_stats (sum x, sum x^2) and bn_bwd (sum dz, sum dz*xhat)
 // partial layout: ws[blk][2][C]
 // ------------------------------------------------------------------------------------------------
-static inline int red_blocks(long P, int C) {
+static inline int red_blocks(long P, int C) {     // upper bound of the partial rows (sizes the workspaces)
   long nb = (P * C) / 4096;              // 16 float4 per thread: the small (deep-level) tensors are latency-bound, not bandwidth-bound
   if (nb > 1024) nb = 1024;
   if (nb < 1) nb = 1;
   return (int)nb;
 }
 
+// A reducing / applying block owns a SLAB of min(C, 32) adjacent channels (one 128-byte line per pixel: LP = 8 float4 lanes,
+// 32 pixels per pass of the block) and a range of pixels; block -> (slab, range) with the slab innermost, so the blocks that
+// run together read the same lines.  The partials of a channel then have as many rows as there are pixel RANGES (32-512), not
+// blocks: few enough that the kernel which consumes the statistics sums them itself (bn_block_sums) instead of waiting
+// for a finalise launch of its own -- 22 launches of 5-8 us each on the train step's critical path.
+struct RedPlan { int sw, nslab, lp, rows; long ppr; };     // slab width (channels), slabs, float4 lanes per pixel, rows, pixels per row
+static RedPlan red_plan(long P, int C) {
+  RedPlan r;
+  r.sw = C < 32 ? C : 32;
+  r.nslab = C / r.sw;
+  r.lp = r.sw / 4;
+  long cap = svs_tune(SVS_TUNE_BN_BLOCKS) > 0 ? svs_tune(SVS_TUNE_BN_BLOCKS) : 512;
+  if (cap > 1024) cap = 1024;                       // (red_blocks: the workspaces' bound)
+  long nb = (P * C) / 4096;
+  if (nb > cap) nb = cap;
+  long rows = nb / r.nslab;
+  if (rows < 1) rows = 1;
+  r.ppr = (P + rows - 1) / rows;
+  r.rows = (int)((P + r.ppr - 1) / r.ppr);          // (no empty rows)
+  return r;
+}
+static inline int red_rows(long P, int C) { return red_plan(P, C).rows; }
+
 struct BnCtx {
   const float* raw; long ldr; long P; int C; long pps;    // pps: pixels per sample (dropout index)
   const float* gamma; const float* beta; const float* mean; const float* invstd;
   float slope; const float* drop;
   const float* dy; long lddy;
+  int nslab, lp; long ppr;                                // RedPlan
 };
+static inline void set_plan(BnCtx& p, const RedPlan& r) { p.nslab = r.nslab; p.lp = r.lp; p.ppr = r.ppr; }
 
-// MODE 0: stats of raw.  MODE 1: backward sums.
+// MODE 0: stats of raw.  MODE 1: backward sums.  partial[row][2][C]
 template <int MODE>
-__global__ __launch_bounds__(256) void channel_reduce_kernel(BnCtx p, float* __restrict__ partial, long pix_per_block) {
+__global__ __launch_bounds__(256) void channel_reduce_kernel(BnCtx p, float* __restrict__ partial) {
   __shared__ f32x4 red[2][256];
-  const int G = p.C >> 2;
   const int t = threadIdx.x;
-  const int cg = t % G, pl = t / G;
-  const int PL = 256 / G;
-  const long p0 = (long)blockIdx.x * pix_per_block;
-  long p1 = p0 + pix_per_block;
+  const int slab = blockIdx.x % p.nslab, row = blockIdx.x / p.nslab;
+  const int l = t % p.lp, pr = t / p.lp, PPB = 256 / p.lp;
+  const int c = slab * (p.lp * 4) + l * 4;
+  const long p0 = (long)row * p.ppr;
+  long p1 = p0 + p.ppr;
   if (p1 > p.P) p1 = p.P;
   f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
   f32x4 mean4, k4, beta4, inv4;
   if (MODE == 1) {
-    mean4 = *(const f32x4*)(p.mean + cg * 4);
-    inv4 = *(const f32x4*)(p.invstd + cg * 4);
-    k4 = *(const f32x4*)(p.gamma + cg * 4) * inv4;
-    beta4 = *(const f32x4*)(p.beta + cg * 4);
+    mean4 = *(const f32x4*)(p.mean + c);
+    inv4 = *(const f32x4*)(p.invstd + c);
+    k4 = *(const f32x4*)(p.gamma + c) * inv4;
+    beta4 = *(const f32x4*)(p.beta + c);
   }
-  if (pl < PL) {
 #pragma unroll 4
-    for (long pix = p0 + pl; pix < p1; pix += PL) {        // (unrolled: four pixels' loads in flight per thread)
-      const f32x4 x = *(const f32x4*)(p.raw + pix * p.ldr + cg * 4);
-      if (MODE == 0) {
-        s0 += x;
-        s1 += x * x;
-      } else {
-        f32x4 dz = *(const f32x4*)(p.dy + pix * p.lddy + cg * 4);
-        if (p.drop) dz *= *(const f32x4*)(p.drop + (long)((unsigned)pix / (unsigned)p.pps) * p.C + cg * 4);     // (P < 2^31: 32-bit division)
-        const f32x4 xm = x - mean4;
-        const f32x4 z = xm * k4 + beta4;
+  for (long pix = p0 + pr; pix < p1; pix += PPB) {        // (unrolled: four pixels' loads in flight per thread)
+    const f32x4 x = *(const f32x4*)(p.raw + pix * p.ldr + c);
+    if (MODE == 0) {
+      s0 += x;
+      s1 += x * x;
+    } else {
+      f32x4 dz = *(const f32x4*)(p.dy + pix * p.lddy + c);
+      if (p.drop) dz *= *(const f32x4*)(p.drop + (long)((unsigned)pix / (unsigned)p.pps) * p.C + c);     // (P < 2^31: 32-bit division)
+      const f32x4 xm = x - mean4;
+      const f32x4 z = xm * k4 + beta4;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) dz[k] = z[k] > 0.f ? dz[k] : dz[k] * p.slope;
-        s0 += dz;
-        s1 += dz * (xm * inv4);
-      }
+      for (int k = 0; k < 4; ++k) dz[k] = z[k] > 0.f ? dz[k] : dz[k] * p.slope;
+      s0 += dz;
+      s1 += dz * (xm * inv4);
     }
   }
   red[0][t] = s0;
   red[1][t] = s1;
   __syncthreads();
-  if (t < G) {
+  if (t < p.lp) {
     f32x4 a = red[0][t], b = red[1][t];
-    for (int j = 1; j < PL; ++j) { a += red[0][j * G + t]; b += red[1][j * G + t]; }
-    float* out = partial + (long)blockIdx.x * 2 * p.C;
-    *(f32x4*)(out + t * 4) = a;
-    *(f32x4*)(out + p.C + t * 4) = b;
+    for (int j = 1; j < PPB; ++j) { a += red[0][j * p.lp + t]; b += red[1][j * p.lp + t]; }
+    float* out = partial + (long)row * 2 * p.C + c;
+    *(f32x4*)out = a;
+    *(f32x4*)(out + p.C) = b;
   }
 }
 
@@ -119,6 +142,84 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   }
 }
 
+// Block-local finalise.  The block's threads are (l, pr) = (float4 lane of the slab, pixel row of a pass); the 256 / lp threads
+// of a lane share the R partial rows of its four channels and fold them in a fixed tree (double accumulation: every block,
+// whatever its index, gets the same bits).  Afterwards sums[which][l][k] holds the totals of channel c0 + 4 l + k.
+__device__ __forceinline__ void bn_block_sums(const float* __restrict__ partial, int R, int C, int c, int lp, double (*sums)[256][4]) {
+  const int t = threadIdx.x, pr = t / lp, PPB = 256 / lp;
+  double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+#pragma unroll 2
+  for (int r = pr; r < R; r += PPB) {
+    const f32x4 x = *(const f32x4*)(partial + (long)r * 2 * C + c);
+    const f32x4 y = *(const f32x4*)(partial + (long)r * 2 * C + C + c);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { a[k] += (double)x[k]; b[k] += (double)y[k]; }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { sums[0][t][k] = a[k]; sums[1][t][k] = b[k]; }
+  __syncthreads();
+  for (int st = PPB >> 1; st > 0; st >>= 1) {
+    if (pr < st) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { sums[0][t][k] += sums[0][t + st * lp][k]; sums[1][t][k] += sums[1][t + st * lp][k]; }
+    }
+    __syncthreads();
+  }
+}
+
+struct BnFin {                        // what bn_finalize_kernel takes, for the apply kernel that does its work
+  const float* partial; int rows; float eps, momentum;
+  float* running_mean; float* running_var; long long* nbt; float* save_mean; float* save_invstd;
+};
+
+// bn_finalize + bn_act_apply in one launch, slab form (see RedPlan).  grid = nslab * ranges; the range-0 block of each slab
+// also writes the saved statistics and the running buffers of its channels.
+__global__ __launch_bounds__(256) void bn_fin_act_apply_kernel(BnCtx p, BnFin f, float* __restrict__ y, long ldy) {
+  __shared__ double sums[2][256][4];
+  __shared__ __attribute__((aligned(16))) float fin[2][32];
+  const int t = threadIdx.x;
+  const int slab = blockIdx.x % p.nslab, row = blockIdx.x / p.nslab;
+  const int l = t % p.lp, pr = t / p.lp, PPB = 256 / p.lp;
+  const int c0 = slab * (p.lp * 4), c = c0 + l * 4;
+  bn_block_sums(f.partial, f.rows, p.C, c, p.lp, sums);
+  if (t < p.lp * 4) {
+    const double mean = sums[0][t >> 2][t & 3] / (double)p.P;
+    double var = sums[1][t >> 2][t & 3] / (double)p.P - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float mf = (float)mean, inv = (float)(1.0 / sqrt(var + (double)f.eps));
+    fin[0][t] = mf;
+    fin[1][t] = inv;
+    if (row == 0) {
+      const int ch = c0 + t;
+      f.save_mean[ch] = mf;
+      f.save_invstd[ch] = inv;
+      if (f.running_mean) {
+        const double unb = p.P > 1 ? var * ((double)p.P / (double)(p.P - 1)) : var;
+        f.running_mean[ch] = (float)((1.0 - f.momentum) * f.running_mean[ch] + f.momentum * mean);
+        f.running_var[ch] = (float)((1.0 - f.momentum) * f.running_var[ch] + f.momentum * unb);
+      }
+      if (f.nbt && blockIdx.x == 0 && t == 0) f.nbt[0] += 1;
+    }
+  }
+  __syncthreads();
+  const f32x4 mean4 = *(const f32x4*)&fin[0][l * 4];
+  const f32x4 k4 = *(const f32x4*)(p.gamma + c) * *(const f32x4*)&fin[1][l * 4];
+  const f32x4 beta4 = *(const f32x4*)(p.beta + c);
+  const long p0 = (long)row * p.ppr;
+  long p1 = p0 + p.ppr;
+  if (p1 > p.P) p1 = p.P;
+  const unsigned pps = (unsigned)p.pps;
+#pragma unroll 4
+  for (long pix = p0 + pr; pix < p1; pix += PPB) {
+    const f32x4 x = *(const f32x4*)(p.raw + pix * p.ldr + c);
+    f32x4 z = (x - mean4) * k4 + beta4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) z[k] = z[k] > 0.f ? z[k] : z[k] * p.slope;
+    if (p.drop) z *= *(const f32x4*)(p.drop + (long)((unsigned)pix / pps) * p.C + c);
+    *(f32x4*)(y + pix * ldy + c) = z;
+  }
+}
+
 // (index arithmetic in 32 bits -- P * C / 4 < 2^32 is checked on the host -- and by shift when C / 4 is a power of two, which it is
 // for every layer of this network: the 64-bit `%` and `/` per float4 made this stream VALU-bound at 4.2 TB/s)
 __global__ __launch_bounds__(256) void bn_act_apply_kernel(BnCtx p, float* __restrict__ y, long ldy, int g_shift) {
@@ -158,45 +259,70 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
 }
 
 // d_raw = k * (dz - mean(dz) - xhat * mean(dz*xhat)); when `partial` is given the block also leaves the per-channel
-// sum of its d_raw values there ([blk][2][C] layout, first half) -- that sum over all blocks is the gradient of the
+// sum of its d_raw values there ([row][2][C] layout, first half) -- that sum over all rows is the gradient of the
 // conv bias in front of this BatchNorm (the reference gets it from autograd; true value 0, what remains is
-// rounding noise), obtained here without a second pass over d_raw.
+// rounding noise), obtained here without a second pass over d_raw.  Slab form (RedPlan).  FIN: the block takes the two
+// means from the reduce pass's partial rows itself (bn_block_sums) instead of from a bn_bwd_finalize launch; the range-0
+// block of each slab then also writes dgamma / dbeta.  `partial` must not be the buffer `sum_rows` points to.
+template <bool FIN>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnCtx p, const float* __restrict__ coef, float* __restrict__ d_raw,
-                                                           float* __restrict__ partial, long pix_per_block) {
+                                                           float* __restrict__ partial, const float* __restrict__ sum_rows, int nrows,
+                                                           float* dgamma, float* dbeta) {
+  __shared__ double sums[2][FIN ? 256 : 1][4];
+  __shared__ __attribute__((aligned(16))) float fin[2][32];
   __shared__ f32x4 red[256];
-  const int G = p.C >> 2;
   const int t = threadIdx.x;
-  const int cg = t % G, pl = t / G, PL = 256 / G;
-  const long p0 = (long)blockIdx.x * pix_per_block;
-  long p1 = p0 + pix_per_block;
+  const int slab = blockIdx.x % p.nslab, row = blockIdx.x / p.nslab;
+  const int l = t % p.lp, pr = t / p.lp, PPB = 256 / p.lp;
+  const int c0 = slab * (p.lp * 4), c = c0 + l * 4;
+  const f32x4 inv4 = *(const f32x4*)(p.invstd + c);
+  const f32x4 mean4 = *(const f32x4*)(p.mean + c);
+  const f32x4 beta4 = *(const f32x4*)(p.beta + c);
+  f32x4 k4, c1, c2;
+  if constexpr (FIN) {
+    bn_block_sums(sum_rows, nrows, p.C, c, p.lp, sums);
+    if (t < p.lp * 4) {
+      const double s = sums[0][t >> 2][t & 3], sx = sums[1][t >> 2][t & 3];
+      fin[0][t] = (float)(s / (double)p.P);
+      fin[1][t] = (float)(sx / (double)p.P);
+      if (row == 0) {
+        if (dbeta) dbeta[c0 + t] = (float)s;
+        if (dgamma) dgamma[c0 + t] = (float)sx;
+      }
+    }
+    __syncthreads();
+    k4 = *(const f32x4*)(p.gamma + c) * inv4;
+    c1 = *(const f32x4*)&fin[0][l * 4];
+    c2 = *(const f32x4*)&fin[1][l * 4];
+  } else {
+    k4 = *(const f32x4*)(coef + c);
+    c1 = *(const f32x4*)(coef + p.C + c);
+    c2 = *(const f32x4*)(coef + 2 * p.C + c);
+  }
+  const long p0 = (long)row * p.ppr;
+  long p1 = p0 + p.ppr;
   if (p1 > p.P) p1 = p.P;
-  const f32x4 inv4 = *(const f32x4*)(p.invstd + cg * 4);
-  const f32x4 k4 = *(const f32x4*)(coef + cg * 4);
-  const f32x4 mean4 = *(const f32x4*)(p.mean + cg * 4);
-  const f32x4 beta4 = *(const f32x4*)(p.beta + cg * 4);
-  const f32x4 c1 = *(const f32x4*)(coef + p.C + cg * 4);
-  const f32x4 c2 = *(const f32x4*)(coef + 2 * p.C + cg * 4);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
-  for (long pix = p0 + pl; pix < p1; pix += PL) {
-    const f32x4 x = *(const f32x4*)(p.raw + pix * p.ldr + cg * 4);
-    f32x4 dz = *(const f32x4*)(p.dy + pix * p.lddy + cg * 4);
-    if (p.drop) dz *= *(const f32x4*)(p.drop + (long)((unsigned)pix / (unsigned)p.pps) * p.C + cg * 4);
+  for (long pix = p0 + pr; pix < p1; pix += PPB) {
+    const f32x4 x = *(const f32x4*)(p.raw + pix * p.ldr + c);
+    f32x4 dz = *(const f32x4*)(p.dy + pix * p.lddy + c);
+    if (p.drop) dz *= *(const f32x4*)(p.drop + (long)((unsigned)pix / (unsigned)p.pps) * p.C + c);
     const f32x4 xm = x - mean4;
     const f32x4 z = xm * k4 + beta4;
 #pragma unroll
     for (int k = 0; k < 4; ++k) dz[k] = z[k] > 0.f ? dz[k] : dz[k] * p.slope;
     const f32x4 r = k4 * (dz - c1 - (xm * inv4) * c2);
-    *(f32x4*)(d_raw + pix * p.C + cg * 4) = r;
+    *(f32x4*)(d_raw + pix * p.C + c) = r;
     acc += r;
   }
   if (partial) {
     red[t] = acc;
     __syncthreads();
-    if (t < G) {
+    if (t < p.lp) {
       f32x4 a = red[t];
-      for (int j = 1; j < PL; ++j) a += red[j * G + t];
-      *(f32x4*)(partial + (long)blockIdx.x * 2 * p.C + t * 4) = a;
+      for (int j = 1; j < PPB; ++j) a += red[j * p.lp + t];
+      *(f32x4*)(partial + (long)row * 2 * p.C + c) = a;
     }
   }
 }
@@ -223,9 +349,9 @@ extern "C" int svs_bn_stats(const float* raw, int64_t ldr, int64_t P, int C, voi
   int rc = check_bn("svs_bn_stats", raw, ldr, P, C);
   if (rc) return rc;
   if (!ws || ws_bytes < svs_bn_workspace_bytes(P, C)) { svs_set_error("svs_bn_stats: workspace too small"); return SVS_ERR_WORKSPACE; }
-  const int nb = red_blocks(P, C);
-  BnCtx p{}; p.raw = raw; p.ldr = ldr; p.P = P; p.C = C;
-  hipLaunchKernelGGL(channel_reduce_kernel<0>, dim3(nb), dim3(256), 0, stream, p, (float*)ws, (P + nb - 1) / nb);
+  const RedPlan rp = red_plan(P, C);
+  BnCtx p{}; p.raw = raw; p.ldr = ldr; p.P = P; p.C = C; set_plan(p, rp);
+  hipLaunchKernelGGL(channel_reduce_kernel<0>, dim3(rp.rows * rp.nslab), dim3(256), 0, stream, p, (float*)ws);
   SVS_CHECK_LAUNCH("bn_stats");
   return SVS_OK;
 }
@@ -233,7 +359,7 @@ extern "C" int svs_bn_stats(const float* raw, int64_t ldr, int64_t P, int C, voi
 extern "C" int svs_bn_finalize(const void* ws, int64_t P, int C, float eps, float momentum, float* running_mean,
                                float* running_var, int64_t* num_batches_tracked, float* save_mean, float* save_invstd,
                                hipStream_t stream) {
-  return svs_bn_finalize_run(ws, red_blocks(P, C), P, C, eps, momentum, running_mean, running_var,
+  return svs_bn_finalize_run(ws, red_rows(P, C), P, C, eps, momentum, running_mean, running_var,
                              (long long*)num_batches_tracked, save_mean, save_invstd, stream);
 }
 
@@ -246,7 +372,40 @@ int svs_bn_finalize_run(const void* partial, int nblk, long P, int C, float eps,
   return SVS_OK;
 }
 
-size_t svs_bn_partial_floats(long P, int C) { return (size_t)red_blocks(P, C) * 2 * C; }
+size_t svs_bn_partial_floats(long P, int C) { return (size_t)red_blocks(P, C) * 2 * C; }     // (capacity: an upper bound of the rows)
+int svs_bn_partial_rows(long P, int C) { return red_rows(P, C); }
+
+// Inline finalise (bn_block_sums) pays when the rows a block has to fold are few: rows * 2 * min(C, 32) floats per block.
+// SVS_BN_INLINE: 0 = never (finalise launches as before), n > 0 = row limit; default 128 (same-device A/B of the batch-64 train
+// step: off 3.409 ms, 128 rows 3.381, 512 rows 3.384, 2048 rows 3.404 -- the shallow levels' 512-1024 rows cost a block more than
+// the launch they save).
+static bool fin_inline(int rows, int C) {
+  const long lim = svs_tune(SVS_TUNE_BN_INLINE) >= 0 ? svs_tune(SVS_TUNE_BN_INLINE) : 128;
+  return rows <= lim && C >= 4 && (C <= 32 ? 256 % (C / 4) == 0 : C % 32 == 0);
+}
+
+// svs_bn_finalize + svs_bn_act_apply; one launch when the partial rows are few enough (fin_inline)
+int svs_bn_fin_act_apply_run(const void* partial, int rows, const float* raw, long ldr, long P, int C, long pixels_per_sample,
+                             const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                             float* running_var, long long* nbt, float* save_mean, float* save_invstd, float slope,
+                             const float* drop, float* y, long ldy, hipStream_t stream) {
+  int rc = check_bn("svs_bn_fin_act_apply", raw, ldr, P, C);
+  if (rc) return rc;
+  SVS_REQUIRE(partial && rows > 0 && save_mean && save_invstd, "svs_bn_fin_act_apply: bad arguments");
+  SVS_REQUIRE(y && ldy >= C && ldy % 4 == 0 && svs_aligned16(y), "svs_bn_fin_act_apply: bad output view");
+  if (!fin_inline(rows, C)) {
+    if ((rc = svs_bn_finalize_run(partial, rows, P, C, eps, momentum, running_mean, running_var, nbt, save_mean, save_invstd, stream))) return rc;
+    return svs_bn_act_apply(raw, ldr, P, C, pixels_per_sample, gamma, beta, save_mean, save_invstd, slope, drop, y, ldy, stream);
+  }
+  SVS_REQUIRE(pixels_per_sample > 0 && pixels_per_sample < (1L << 31), "svs_bn_fin_act_apply: bad pixels_per_sample");
+  const RedPlan rp = red_plan(P, C);
+  BnCtx p{}; p.raw = raw; p.ldr = ldr; p.P = P; p.C = C; p.pps = pixels_per_sample; set_plan(p, rp);
+  p.gamma = gamma; p.beta = beta; p.slope = slope; p.drop = drop;
+  BnFin f{(const float*)partial, rows, eps, momentum, running_mean, running_var, nbt, save_mean, save_invstd};
+  hipLaunchKernelGGL(bn_fin_act_apply_kernel, dim3(rp.rows * rp.nslab), dim3(256), 0, stream, p, f, y, ldy);
+  SVS_CHECK_LAUNCH("bn_fin_act_apply");
+  return SVS_OK;
+}
 
 extern "C" int svs_bn_act_apply(const float* raw, int64_t ldr, int64_t P, int C, int64_t pixels_per_sample,
                                 const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
@@ -288,23 +447,30 @@ int svs_bn_bwd_run(const float* dy, long lddy, const float* raw, long ldr, long 
   if (rc) return rc;
   SVS_REQUIRE(dy && d_raw && lddy >= C && lddy % 4 == 0 && svs_aligned16(dy) && svs_aligned16(d_raw), "svs_bn_bwd: bad gradient view");
   if (!ws || ws_bytes < svs_bn_workspace_bytes(P, C)) { svs_set_error("svs_bn_bwd: workspace too small"); return SVS_ERR_WORKSPACE; }
-  const int nb = red_blocks(P, C);
+  const RedPlan rp = red_plan(P, C);
+  const int nb = rp.rows, grid = rp.rows * rp.nslab;
   float* partial = (float*)ws;
   float* coef = partial + (size_t)nb * 2 * C;
-  BnCtx p{}; p.raw = raw; p.ldr = ldr; p.P = P; p.C = C; p.pps = pixels_per_sample;
+  BnCtx p{}; p.raw = raw; p.ldr = ldr; p.P = P; p.C = C; p.pps = pixels_per_sample; set_plan(p, rp);
   p.gamma = gamma; p.beta = beta; p.mean = save_mean; p.invstd = save_invstd; p.slope = slope; p.drop = drop;
   p.dy = dy; p.lddy = lddy;
-  hipLaunchKernelGGL(channel_reduce_kernel<1>, dim3(nb), dim3(256), 0, stream, p, partial, (P + nb - 1) / nb);
+  hipLaunchKernelGGL(channel_reduce_kernel<1>, dim3(grid), dim3(256), 0, stream, p, partial);
   SVS_CHECK_LAUNCH("bn_bwd_reduce");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C / 4), dim3(256), 0, stream, (const float*)partial, nb, (long)P, C,
-                     gamma, save_invstd, dgamma, dbeta, coef);
-  SVS_CHECK_LAUNCH("bn_bwd_finalize");
-  // the apply pass reuses the partial buffer of the reduce pass (already consumed by the finalize kernel) unless the
-  // caller keeps the bias-gradient partials for a deferred, batched final pass
   const bool deferred = dbias && dbias_partial && defer && defer->njobs < 12;
+  // the apply pass reuses the partial buffer of the reduce pass (already consumed by the finalize kernel) unless the
+  // caller keeps the bias-gradient partials for a deferred, batched final pass -- which the inline finalise needs too:
+  // its blocks still read the reduce pass's rows while others write theirs
   float* bpart = deferred ? dbias_partial : partial;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nb), dim3(256), 0, stream, p, (const float*)coef, d_raw, dbias ? bpart : nullptr,
-                     (P + nb - 1) / nb);
+  if (fin_inline(nb, C) && (!dbias || deferred)) {
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(grid), dim3(256), 0, stream, p, (const float*)nullptr, d_raw, dbias ? bpart : nullptr,
+                       (const float*)partial, nb, dgamma, dbeta);
+  } else {
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C / 4), dim3(256), 0, stream, (const float*)partial, nb, (long)P, C,
+                       gamma, save_invstd, dgamma, dbeta, coef);
+    SVS_CHECK_LAUNCH("bn_bwd_finalize");
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(grid), dim3(256), 0, stream, p, (const float*)coef, d_raw, dbias ? bpart : nullptr,
+                       (const float*)nullptr, 0, (float*)nullptr, (float*)nullptr);
+  }
   SVS_CHECK_LAUNCH("bn_bwd_apply");
   if (deferred) {
     const int j = defer->njobs++;
@@ -346,7 +512,7 @@ int svs_channel_sum_finalize_multi_run(const SvsSumJobs& jobs, hipStream_t strea
 int svs_channel_sum_run(const float* x, long ldx, long P, int C, float* out, void* ws, size_t ws_bytes, hipStream_t stream) {
   int rc = svs_bn_stats(x, ldx, P, C, ws, ws_bytes, stream);
   if (rc) return rc;
-  hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3(C / 4), dim3(256), 0, stream, (const float*)ws, red_blocks(P, C), C, out);
+  hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3(C / 4), dim3(256), 0, stream, (const float*)ws, red_rows(P, C), C, out);
   SVS_CHECK_LAUNCH("channel_sum_finalize");
   return SVS_OK;
 }

@@ -179,4 +179,11 @@ __device__ __forceinline__ void fft_build_twiddles(float2* tw, int tid, int nthr
     tw[e] = float2{c, s};
   }
 }
+// the block's copy of the device-wide table (fft_tables.hip: the same values, built once): two entries per 16-byte load
+template <int N>
+__device__ __forceinline__ void fft_load_twiddles(float2* tw, const float2* __restrict__ table, int tid, int nthreads) {
+  static_assert(FftSize<N>::TW % 2 == 0, "table length");
+  typedef float fft_f4 __attribute__((ext_vector_type(4)));
+  for (int e = tid; e < FftSize<N>::TW / 2; e += nthreads) ((fft_f4*)tw)[e] = ((const fft_f4*)table)[e];
+}
 #endif

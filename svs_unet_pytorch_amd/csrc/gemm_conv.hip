@@ -856,6 +856,49 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
   }
 }
 
+// The same sum for a layer whose BatchNorm statistics are wanted, in the slab form of elementwise.hip's RedPlan: a block owns
+// 32 adjacent channels (one 128-byte line per pixel and slab) and a range of `ppr` pixels, block -> (slab, range) with the slab
+// innermost, and leaves stats[range][2][N] -- as many partial rows per channel as there are pixel ranges (8-64 on the deep
+// levels that run split-K), few enough for the BatchNorm apply kernel to fold them itself.  N % 32 == 0.
+__global__ __launch_bounds__(256) void splitk_epilogue_stats_kernel(const float* __restrict__ slab, int ksplit, long P, int N,
+                                                                    const float* __restrict__ bias, float* __restrict__ y, long ldy,
+                                                                    float* __restrict__ stats, long ppr,
+                                                                    const unsigned char* __restrict__ rowsplit) {
+  __shared__ f32x4 red[2][256];
+  const int nslab = N >> 5, t = threadIdx.x;
+  const int sl = blockIdx.x % nslab, row = blockIdx.x / nslab;
+  const int l = t & 7, pr = t >> 3;
+  const int n = sl * 32 + l * 4;
+  const long stride = P * N;
+  const long p0 = (long)row * ppr;
+  long p1 = p0 + ppr;
+  if (p1 > P) p1 = P;
+  f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+  if (bias) b4 = *(const f32x4*)(bias + n);
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+  for (long pix = p0 + pr; pix < p1; pix += 32) {
+    const long e = pix * N + n;
+    f32x4 s = *(const f32x4*)(slab + e);
+    const int nz = rowsplit ? (int)rowsplit[pix] : ksplit;
+#pragma unroll 4
+    for (int z = 1; z < nz; ++z) s += *(const f32x4*)(slab + z * stride + e);         // (same order as splitk_epilogue_kernel)
+    if (bias) s += b4;
+    *(f32x4*)(y + pix * ldy + n) = s;
+    s0 += s;
+    s1 += s * s;
+  }
+  red[0][t] = s0;
+  red[1][t] = s1;
+  __syncthreads();
+  if (t < 8) {
+    f32x4 a = red[0][t], b = red[1][t];
+    for (int j = 1; j < 32; ++j) { a += red[0][j * 8 + t]; b += red[1][j * 8 + t]; }
+    float* out = stats + (long)row * 2 * N + n;
+    *(f32x4*)out = a;
+    *(f32x4*)(out + N) = b;
+  }
+}
+
 // ---- host side ---------------------------------------------------------------------------------
 struct ConvPlan { int cfg; int BM, BN; int ksplit; long mtiles; int grid_y; int pf; };
 
@@ -1282,6 +1325,21 @@ int svs_conv_gemm_run(int mode, const float* x, long ldx, int B, int H, int W, i
     if (fuse && (long)grid * 2 * N > stats_cap) grid = stats_cap / (2 * N);
     int n_shift = -1;
     if ((N & (N - 1)) == 0) { n_shift = 0; while ((1 << n_shift) < N) ++n_shift; }
+    if (fuse && N % 32 == 0 && svs_tune(SVS_TUNE_BN_INLINE) != 0) {
+      // slab form: blocks = slabs x pixel ranges, at most 512 (two per CU), a range no shorter than one pass of 32 pixels
+      const int nslab = N / 32;
+      long rows = 512 / nslab;
+      if (rows > (P + 31) / 32) rows = (P + 31) / 32;
+      if (rows * 2 * N > stats_cap) rows = stats_cap / (2 * N);
+      if (rows < 1) rows = 1;
+      const long ppr = (P + rows - 1) / rows;
+      rows = (P + ppr - 1) / ppr;
+      hipLaunchKernelGGL(splitk_epilogue_stats_kernel, dim3((unsigned)(rows * nslab)), dim3(256), 0, stream, a.slab, pl.ksplit, P, N, bias,
+                         y, ldy, stats, ppr, bal.enabled ? bal.rowsplit : nullptr);
+      SVS_CHECK_LAUNCH("splitk_epilogue_stats");
+      *stats_nblk = (int)rows;
+      return SVS_OK;
+    }
     hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(grid), dim3(256), 0, stream, a.slab, pl.ksplit, P, N, bias, scale,
                        shift, slope, y, ldy, accumulate, fuse ? stats : nullptr, n_shift, bal.enabled ? bal.rowsplit : nullptr);
     SVS_CHECK_LAUNCH("splitk_epilogue");

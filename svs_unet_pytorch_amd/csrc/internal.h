@@ -13,9 +13,15 @@ int svs_conv_gemm_run(int mode, const float* x, long ldx, int B, int H, int W, i
 // of rows (0: not produced, e.g. the LDS-free direct kernel).
 int svs_bn_finalize_run(const void* partial, int nblk, long P, int C, float eps, float momentum, float* running_mean,
                         float* running_var, long long* nbt, float* save_mean, float* save_invstd, hipStream_t stream);
+// svs_bn_finalize + svs_bn_act_apply of `rows` partial rows; one launch when the rows are few enough for a block-local finalise
+int svs_bn_fin_act_apply_run(const void* partial, int rows, const float* raw, long ldr, long P, int C, long pixels_per_sample,
+                             const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                             float* running_var, long long* nbt, float* save_mean, float* save_invstd, float slope,
+                             const float* drop, float* y, long ldy, hipStream_t stream);
 struct SvsSumJobs { int njobs; const float* partial[12]; int nblk[12]; int C[12]; float* out[12]; };
 int svs_channel_sum_finalize_multi_run(const SvsSumJobs& jobs, hipStream_t stream);
-size_t svs_bn_partial_floats(long P, int C);
+size_t svs_bn_partial_floats(long P, int C);     // capacity of a partial buffer
+int svs_bn_partial_rows(long P, int C);         // rows svs_bn_stats writes
 size_t svs_conv_gemm_workspace(int mode, int B, int H, int W, int C, int Ho, int Wo, int N);
 
 int svs_wgrad_gemm_run(const float* s, long lds, int B, int Hs, int Ws, int Cs, const float* l, long ldl, int Hl,
@@ -51,6 +57,10 @@ int svs_bn_bwd_run(const float* dy, long lddy, const float* raw, long ldr, long 
 // dbias_partial + defer: the per-block sums of d_raw go to dbias_partial (svs_bn_partial_floats(P, C) floats, must
 // stay untouched until the deferred pass) and the final reduction into dbias is appended to *defer instead of being
 // launched -- the caller runs svs_channel_sum_finalize_multi_run once for all layers.
+
+// device pointer to fft_wave.h's twiddle table for n_fft = 512 / 1024 / 2048 (FftSize<n>::TW float2), built once per device;
+// work queued on `stream` after the call sees the table complete
+int svs_fft_twiddles(int n, hipStream_t stream, const float2** out);
 
 int svs_conv_gemm_describe(int mode, int B, int H, int W, int C, int Ho, int Wo, int N, long ldx, char* buf, size_t n);
 int svs_wgrad_gemm_describe(int B, int Hs, int Ws, int Cs, int Cl, char* buf, size_t n);

@@ -49,6 +49,7 @@ struct MrArgs {
   float* partial;                                    // [B * gridDim.x][3]
   const float* coef;                                 // [1 + B]: log-magnitude coefficient, then the SC coefficient of every waveform (device)
   float* frames;                                     // [B][ceil(F / 16)][15 hop + win]: the blocks' overlap-added frame gradients ("segments")
+  const float2* twiddles;                            // this n_fft's table (svs_fft_twiddles)
 };
 
 // periodic Hann window of `win` samples, centred inside n_fft (torch.stft pads a short window on both sides), sample j of the
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(64 * MrCfg<N>::WAVES) void mr_sums_kernel(MrArgs p)
   float* const red = (float*)(tw + TW);              // [WV][3]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.y, t = blockIdx.x * WV + wave;
-  fft_build_twiddles<N>(tw, tid, 64 * WV);
+  fft_load_twiddles<N>(tw, p.twiddles, tid, 64 * WV);
   float2* const buf = fbuf + wave * BUF;
   mr_fill<N>(buf, p, b, t, lane);
   __syncthreads();
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(64 * MrCfg<N>::WAVES) void mr_pass_kernel(MrArgs p)
   float* const red = (float*)(tw + TW);              // [WV][3]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.y, t = blockIdx.x * WV + wave;
-  fft_build_twiddles<N>(tw, tid, 64 * WV);
+  fft_load_twiddles<N>(tw, p.twiddles, tid, 64 * WV);
   float2* const buf = fbuf + wave * BUF;
   mr_fill<N>(buf, p, b, t, lane);                    // (zeros past the last frame)
   __syncthreads();
@@ -347,7 +348,9 @@ extern "C" int svs_mrstft_loss_fwd_bwd(const float* x, const float* y, int B, in
   const bool grad = d_x != nullptr;
   MrOlaArgs o{};
   for (int r = 0; r < MR_NRES; ++r) {
-    a[r] = MrArgs{x, y, B, (long)L, MR_HOP[r], MR_WIN[r], (int)(1 + L / MR_HOP[r]), w.partial[r], w.coef + (size_t)r * (1 + B), w.frames[r]};
+    const float2* twiddles = nullptr;
+    if ((rc = svs_fft_twiddles(MR_NFFT[r], stream, &twiddles))) return rc;
+    a[r] = MrArgs{x, y, B, (long)L, MR_HOP[r], MR_WIN[r], (int)(1 + L / MR_HOP[r]), w.partial[r], w.coef + (size_t)r * (1 + B), w.frames[r], twiddles};
     rc = MR_NFFT[r] == 1024 ? mr_launch<1024>(grad, a[r], B, stream) : MR_NFFT[r] == 2048 ? mr_launch<2048>(grad, a[r], B, stream)
                                                                                              : mr_launch<512>(grad, a[r], B, stream);
     if (rc) return rc;

@@ -37,7 +37,7 @@ extern "C" const char* svs_last_error_string(void) { return g_err; }
 // ---------------------------------------------------------------------------------------------
 static const char* const TUNE_NAMES[SVS_TUNE_COUNT] = {
     "CONV_CFG", "CONV_KSPLIT", "CONV_WINDOW", "CONV_SKIP", "CONV_KORDER", "CONV_DIRECT", "SKIP_REDUCE", "WGRAD_CFG",
-    "WGRAD_KSPLIT", "WGRAD_SKIP", "WGRAD_WINDOW", "WGRAD_C1_VALU", "SIDE_PRIORITY", "TRAIN_UNFUSED", "TRAIN_ONE_STREAM", "CONV_PLAN", "MFMA_SPLIT", "CONV_BALANCE", "CONV_C1_TILED", "BF16_KB", "BF16_CFG", "BF16_KSPLIT", "CONV_PF", "WGRAD_PF"};
+    "WGRAD_KSPLIT", "WGRAD_SKIP", "WGRAD_WINDOW", "WGRAD_C1_VALU", "SIDE_PRIORITY", "TRAIN_UNFUSED", "TRAIN_ONE_STREAM", "CONV_PLAN", "MFMA_SPLIT", "CONV_BALANCE", "CONV_C1_TILED", "BF16_KB", "BF16_CFG", "BF16_KSPLIT", "CONV_PF", "WGRAD_PF", "BN_INLINE", "BN_BLOCKS"};
 static std::atomic<long> g_tune[SVS_TUNE_COUNT];      // written by svs_tuning_set while compute threads read: relaxed atomics
 static std::once_flag g_tune_once;
 static void tune_load_env() {
@@ -532,16 +532,14 @@ static int train_forward_impl(const ParamView& v, float* bn_buffers, int64_t* nb
     const int l = k - 1;
     if (!stat_rows) {
       if ((rc = svs_bn_stats(t.raw_e[k], CH[k], g.P[k], CH[k], t.bnws, t.bnws_bytes, stream))) return rc;
-      stat_rows = (int)(svs_bn_partial_floats(g.P[k], CH[k]) / (2 * CH[k]));
+      stat_rows = svs_bn_partial_rows(g.P[k], CH[k]);
     }
-    if ((rc = svs_bn_finalize_run(t.bnws, stat_rows, g.P[k], CH[k], BN_EPS, BN_MOMENTUM,
-                                  bn_buffers ? bn_buffers + svs_unet_buffer_offset(l, 0) : nullptr,
-                                  bn_buffers ? bn_buffers + svs_unet_buffer_offset(l, 1) : nullptr,
-                                  nbt ? (long long*)(nbt + l) : nullptr, t.mean[l], t.invstd[l], stream))) return rc;
     const View yo = (k == 6) ? View{t.c6, 512} : cat_half(t.cat, g, k, 1);
     float* y = yo.p; const long ldy = yo.ld;
-    if ((rc = svs_bn_act_apply(t.raw_e[k], CH[k], g.P[k], CH[k], (long)g.h[k] * g.w[k], v.gamma[l], v.beta[l], t.mean[l],
-                               t.invstd[l], LEAKY, nullptr, y, ldy, stream))) return rc;
+    if ((rc = svs_bn_fin_act_apply_run(t.bnws, stat_rows, t.raw_e[k], CH[k], g.P[k], CH[k], (long)g.h[k] * g.w[k], v.gamma[l], v.beta[l],
+                                       BN_EPS, BN_MOMENTUM, bn_buffers ? bn_buffers + svs_unet_buffer_offset(l, 0) : nullptr,
+                                       bn_buffers ? bn_buffers + svs_unet_buffer_offset(l, 1) : nullptr,
+                                       nbt ? (long long*)(nbt + l) : nullptr, t.mean[l], t.invstd[l], LEAKY, nullptr, y, ldy, stream))) return rc;
   }
   // decoder: convT (+bias) -> raw; batch stats; BN + ReLU + Dropout2d -> first half of cat[lout]
   const float* dp = drop;
@@ -555,15 +553,13 @@ static int train_forward_impl(const ParamView& v, float* bn_buffers, int64_t* nb
     if (rc) return rc;
     if (!stat_rows) {
       if ((rc = svs_bn_stats(t.raw_d[j], DEC_N[j], g.P[lout], DEC_N[j], t.bnws, t.bnws_bytes, stream))) return rc;
-      stat_rows = (int)(svs_bn_partial_floats(g.P[lout], DEC_N[j]) / (2 * DEC_N[j]));
+      stat_rows = svs_bn_partial_rows(g.P[lout], DEC_N[j]);
     }
-    if ((rc = svs_bn_finalize_run(t.bnws, stat_rows, g.P[lout], DEC_N[j], BN_EPS, BN_MOMENTUM,
-                                  bn_buffers ? bn_buffers + svs_unet_buffer_offset(l, 0) : nullptr,
-                                  bn_buffers ? bn_buffers + svs_unet_buffer_offset(l, 1) : nullptr,
-                                  nbt ? (long long*)(nbt + l) : nullptr, t.mean[l], t.invstd[l], stream))) return rc;
     const View yo = cat_half(t.cat, g, lout, 0);
-    if ((rc = svs_bn_act_apply(t.raw_d[j], DEC_N[j], g.P[lout], DEC_N[j], (long)g.h[lout] * g.w[lout], v.gamma[l], v.beta[l],
-                               t.mean[l], t.invstd[l], 0.f, dp, yo.p, yo.ld, stream))) return rc;
+    if ((rc = svs_bn_fin_act_apply_run(t.bnws, stat_rows, t.raw_d[j], DEC_N[j], g.P[lout], DEC_N[j], (long)g.h[lout] * g.w[lout], v.gamma[l],
+                                       v.beta[l], BN_EPS, BN_MOMENTUM, bn_buffers ? bn_buffers + svs_unet_buffer_offset(l, 0) : nullptr,
+                                       bn_buffers ? bn_buffers + svs_unet_buffer_offset(l, 1) : nullptr,
+                                       nbt ? (long long*)(nbt + l) : nullptr, t.mean[l], t.invstd[l], 0.f, dp, yo.p, yo.ld, stream))) return rc;
     if (dp) dp += (long)B * DEC_N[j];
   }
   return svs_deconv_to1_run(t.cat[1], 16, B, g.h[1], g.w[1], 32, v.w[11], v.b[11], mask, g.h[0], g.w[0], 1, stream,

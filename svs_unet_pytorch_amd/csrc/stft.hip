@@ -86,6 +86,7 @@ struct StftArgs {
   float* absmax_partial;                                            // [gridDim.y * gridDim.x] or null
   // SINK_DMAG: d_logit[idx] += alpha * d|S| * mix[idx] * mask[idx] * (1 - mask[idx]), all in layout `lay`
   const float* angle; const float* mix; const float* mask; float* d_logit; float alpha;
+  const float2* twiddles;                                           // svs_fft_twiddles(NFFT): the device-wide table
 };
 
 template <int SRC, int SINK>
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(512) void stft_fwd_kernel(StftArgs p) {
       }
     }
   }
-  fft_build_twiddles<NFFT>(tw, tid, 512);
+  fft_load_twiddles<NFFT>(tw, p.twiddles, tid, 512);
   __syncthreads();                                          // twiddles (and staged angles) are complete
   const float2* const tw2 = tw + FftSize<NFFT>::TW1;
 #pragma unroll
@@ -242,6 +243,7 @@ struct IstftArgs {
   int channels, T, hop;
   float* y; long n_out;                           // (channels, hop * (T - 1))
   float* absmax_partial;
+  const float2* twiddles;                         // svs_fft_twiddles(NFFT)
 };
 
 // A 512-thread block (8 waves) owns the padded samples [hop * t0, hop * (t0 + 15)) of one channel: exactly the 16 frames
@@ -307,7 +309,7 @@ __global__ __launch_bounds__(512, 2) void istft_kernel(IstftArgs p, int ngroups)
       pb[PMODE == 1 ? r : 0] = float2{vb.x, vb.y};
     }
   }
-  fft_build_twiddles<NFFT>(tw, tid, 512);
+  fft_load_twiddles<NFFT>(tw, p.twiddles, tid, 512);
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int k = (tid >> 4) + (512 / NF) * it, f = tid & (NF - 1);
@@ -427,7 +429,7 @@ __global__ __launch_bounds__(512) void istft_general_kernel(IstftArgs p, int ngr
   const __amdgpu_buffer_rsrc_t rmask = __builtin_amdgcn_make_buffer_rsrc((void*)(p.mask ? p.mask : p.mag), 0, OOB, 0x00020000);
   const __amdgpu_buffer_rsrc_t rph = __builtin_amdgcn_make_buffer_rsrc((void*)p.phase, 0, OOB, 0x00020000);
   const bool has_mask = p.mask != nullptr;
-  fft_build_twiddles<NFFT>(tw, tid, 512);
+  fft_load_twiddles<NFFT>(tw, p.twiddles, tid, 512);
   for (int i = tid; i < seg_len; i += 512) acc[i] = float2{0.f, 0.f};
   for (int r = 0; r < rounds; ++r) {
     const int tb = t0 - halo + NF * r;                      // first frame of this round
@@ -584,6 +586,7 @@ extern "C" int svs_stft_tiles(const float* y, int64_t n_samples, int channels, i
   a.y = y; a.n_samples = n_samples; a.channels = channels; a.hop = hop; a.T = T;
   a.mag = mag; a.lay = SpecLayout{chan_stride, seg, rows, first_bin, frames_alloc};
   a.phase = phase; a.phase_mode = phase_mode; a.absmax_partial = absmax_partial;
+  if ((rc = svs_fft_twiddles(NFFT, stream, &a.twiddles))) return rc;
   const size_t lds = fwd_lds_bytes(false);
   if ((rc = allow_lds(stft_fwd_kernel<SRC_SIGNAL, SINK_MAGPHASE>, lds))) return rc;
   dim3 grid((unsigned)((frames_alloc + GROUP - 1) / GROUP), (unsigned)channels);
@@ -632,6 +635,7 @@ extern "C" int svs_istft_tiles(const float* mag, int64_t chan_stride, int seg, i
   a.mask = mask; a.invert = invert; a.phase = phase; a.phase_mode = phase_mode;
   a.channels = channels; a.T = frames; a.hop = hop; a.y = y; a.n_out = (long)hop * (frames - 1);
   a.absmax_partial = absmax_partial;
+  if ((rc = svs_fft_twiddles(NFFT, stream, &a.twiddles))) return rc;
   const int ngroups = svs_istft_groups_per_channel(hop, frames);
   const long total = (long)ngroups * channels;
   const dim3 grid((unsigned)total);
@@ -690,6 +694,7 @@ extern "C" int svs_istft_bwd_mask(const float* d_wav, const float* angle, const 
   const size_t lds = fwd_lds_bytes(true);
   int rc = allow_lds(stft_fwd_kernel<SRC_ENVDIV, SINK_DMAG>, lds);
   if (rc) return rc;
+  if ((rc = svs_fft_twiddles(NFFT, stream, &a.twiddles))) return rc;
   dim3 grid((unsigned)((frames + GROUP - 1) / GROUP), (unsigned)B);
   hipLaunchKernelGGL((stft_fwd_kernel<SRC_ENVDIV, SINK_DMAG>), grid, dim3(512), lds, stream, a);
   SVS_CHECK_LAUNCH("istft_bwd");
