@@ -497,9 +497,18 @@ def test_single_channel_wgrad_mfma(B, H, W, report):
     assert report(f"deconv6 wgrad (MFMA) B{B} {H}x{W}", relerr(dw, w.grad), 2e-5)
 
 
+@pytest.mark.parametrize("inline", [-1, 0], ids=["inline-finalise", "finalise-launch"])     # svs_bn_bwd: the apply kernel folds the partial rows itself / bn_bwd_finalize launch
 @pytest.mark.parametrize("B,H,W,C,slope,use_drop", [(4, 16, 8, 64, 0.2, False), (3, 8, 4, 256, 0.0, True), (2, 64, 32, 16, 0.2, False),
-                                                     (2, 4, 2, 512, 0.0, True)])
-def test_bn_train_fwd_bwd(B, H, W, C, slope, use_drop, report):
+                                                     (2, 4, 2, 512, 0.0, True), (16, 64, 64, 16, 0.2, False)])     # (the last: 256 partial rows, above the inline limit)
+def test_bn_train_fwd_bwd(B, H, W, C, slope, use_drop, inline, report):
+    _lib.tuning("BN_INLINE", inline)
+    try:
+        _bn_train_fwd_bwd(B, H, W, C, slope, use_drop, report)
+    finally:
+        _lib.tuning("BN_INLINE", -1)
+
+
+def _bn_train_fwd_bwd(B, H, W, C, slope, use_drop, report):
     x = (rnd((B, C, H, W), 80) * 2 + 0.3).double().requires_grad_(True)
     gamma = rnd((C,), 81, 0.5, 1.5).double().requires_grad_(True)
     beta = rnd((C,), 82, -0.2, 0.2).double().requires_grad_(True)
