@@ -31,6 +31,14 @@ int svs_fft_twiddles(int n, hipStream_t stream, const float2** out) {
   SVS_REQUIRE(dev >= 0 && dev < 64, "svs_fft_twiddles: device index %d", dev);
   std::lock_guard<std::mutex> guard(g_mu);
   TabState& t = g_tab[dev];
+  if (t.state != 2) {                 // (state 2 needs no stream operation at all and is safe inside a capture)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) {
+      svs_set_error("svs_fft_twiddles: the first transform of a process must run outside a stream capture (it builds the twiddle tables)");
+      return SVS_ERR_INVALID;
+    }
+    (void)hipGetLastError();
+  }
   if (t.state == 0) {
     void* p = nullptr;
     SVS_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(g_fft_twiddles)));
