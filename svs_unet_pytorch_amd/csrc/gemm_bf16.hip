@@ -601,6 +601,106 @@ __global__ __launch_bounds__(256) void conv2_window_bf16_kernel(Conv2WinArgs p) 
     }
   }
 }
+// conv3 (32 -> 64 channels, stride-2 gather) in the same LDS-window form.  In the GEMM form every input pixel goes through L2 /
+// LDS 6.25 times (4.6x the algorithmic HBM bytes by the counters, 89 us at 216 tiles); here a block owns 8 x 16 output pixels,
+// stages their 19 x 35 input window ONCE (even / odd columns in separate planes so that the 16 pixels of a fragment, two input
+// columns apart, are adjacent slots; 80-byte pixel pitch: conflict-free ds_read_b128), keeps ALL 25 x 64 x 32 weights in LDS for
+// its whole life (100 KB, 16-byte pieces XOR-swizzled by the row; gather-packed bf16 weights [n][tap][c] as the GEMM has them),
+// and every tap is eight MFMAs per wave (2 pixel rows x 4 channel tiles, K = the tap's 32 channels) with both fragments at
+// base + compile-time offset: no barrier and no global access inside a tile.  157 KB of LDS: one persistent block per CU, the next
+// tile's window in flight (registers) during the current tile's MFMAs.
+struct Conv3WinArgs {
+  const u16* x; long ldx; int B, H, W;       // 32 channels at x
+  const u16* wg;                             // [64][25][32] bf16, BatchNorm scale folded in
+  const float* shift; float slope;
+  u16* y; long ldy; int Ho, Wo;              // 64 channels at y
+};
+#define CONV3_WIN_LDS (19 * 2 * 18 * 80 + 25 * 64 * 64)
+__global__ __launch_bounds__(256) void conv3_window_bf16_kernel(Conv3WinArgs p) {
+  constexpr int TH = 8, TW = 16, WR = 2 * TH + 3, WC = 2 * TW + 3, PW = TW + 2, LPB = 80;
+  constexpr int NCH = WR * WC * 4, NST = (NCH + 255) / 256;                       // 16-byte pieces of the window
+  constexpr int WIN_BYTES = WR * 2 * PW * LPB;
+  static_assert(WIN_BYTES + 25 * 64 * 64 == CONV3_WIN_LDS, "LDS size");
+  extern __shared__ __attribute__((aligned(16))) unsigned char c3_smem[];
+  unsigned char* const win = c3_smem;
+  unsigned char* const wts = c3_smem + WIN_BYTES;                                 // [tap][n][64 bytes], piece ^ ((n >> 1) & 3)
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lrow = lane & 15, q = lane >> 4;
+  const int tiles_w = (p.Wo + TW - 1) / TW, tiles_h = (p.Ho + TH - 1) / TH;
+  const int ntiles = p.B * tiles_h * tiles_w;
+  for (int e = t; e < 25 * 64 * 4; e += 256) {                                    // global [n][tap][4 pieces]: contiguous
+    const int piece = e & 3, tap = (e >> 2) % 25, n = e / 100;
+    *(uint4*)(wts + (tap * 64 + n) * 64 + ((piece ^ ((n >> 1) & 3)) * 16)) = *(const uint4*)(p.wg + (long)e * 8);
+  }
+  float sh[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sh[j][r] = p.shift[j * 16 + q * 4 + r];
+  uint4 stage[NST];
+  auto fetch_window = [&](int tile) __attribute__((always_inline)) {
+    const int fow0 = (tile % tiles_w) * TW, foh0 = ((tile / tiles_w) % tiles_h) * TH;
+    const u16* const xb = p.x + (long)(tile / (tiles_w * tiles_h)) * p.H * p.W * p.ldx;
+#pragma unroll
+    for (int k = 0; k < NST; ++k) {
+      const int e = t + k * 256, c4 = e & 3, px = e >> 2;
+      const int wr = px / WC, wc = px - wr * WC;
+      const int ih = 2 * foh0 - 2 + wr, iw = 2 * fow0 - 2 + wc;
+      stage[k] = make_uint4(0u, 0u, 0u, 0u);
+      if (e < NCH && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) stage[k] = *(const uint4*)(xb + ((long)ih * p.W + iw) * p.ldx + c4 * 8);
+    }
+  };
+  if ((int)blockIdx.x < ntiles) fetch_window(blockIdx.x);
+  const unsigned char* const pbase = win + ((8 * wave) * PW + lrow) * LPB + q * 16;       // window row 4 wave (+ 2 i + kh), plane 0, slot lrow
+  const unsigned char* const wbase = wts + lrow * 64 + ((q ^ ((lrow >> 1) & 3)) * 16);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int ow0 = (tile % tiles_w) * TW, oh0 = ((tile / tiles_w) % tiles_h) * TH;
+    const long b = tile / (tiles_w * tiles_h);
+    __syncthreads();                                                               // the previous tile's readers are done (first tile: the weights are staged)
+#pragma unroll
+    for (int k = 0; k < NST; ++k) {
+      const int e = t + k * 256, c4 = e & 3, px = e >> 2;
+      const int wr = px / WC, wc = px - wr * WC;
+      if (e < NCH) *(uint4*)(win + ((wr * 2 + (wc & 1)) * PW + (wc >> 1)) * LPB + c4 * 16) = stage[k];
+    }
+    if (tile + (int)gridDim.x < ntiles) fetch_window(tile + gridDim.x);
+    __syncthreads();
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf_static_for<25>([&](auto tc) {
+      constexpr int tap = decltype(tc)::value, kh = tap / 5, kw = tap % 5;
+      bf16x8 fw[4], fp[2];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fw[j] = __builtin_bit_cast(bf16x8, *(const f32x4*)(wbase + (tap * 64 + j * 16) * 64));
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fp[i] = __builtin_bit_cast(bf16x8, *(const f32x4*)(pbase + (((2 * i + kh) * 2 + (kw & 1)) * PW + (kw >> 1)) * LPB));
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fp[i], acc[i][j], 0, 0, 0);
+    });
+    // D map: column lrow = pixel, rows q*4 + r = channels (+16 j): 4 consecutive channels per lane -> one 8-byte store
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int oh = oh0 + 2 * wave + i, ow = ow0 + lrow;
+      if (oh >= p.Ho || ow >= p.Wo) continue;
+      u16* const dst = p.y + ((b * p.Ho + oh) * p.Wo + ow) * p.ldy + q * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float u = acc[i][j][r] + sh[j][r]; v[r] = u > 0.f ? u : u * p.slope; }
+        uint2 o;
+        o.x = (unsigned)to_bf16(v[0]) | ((unsigned)to_bf16(v[1]) << 16);
+        o.y = (unsigned)to_bf16(v[2]) | ((unsigned)to_bf16(v[3]) << 16);
+        *(uint2*)(dst + j * 16) = o;
+      }
+    }
+  }
+}
+
 // wk[s][n][k]: k = t2*16 + c holds scale[n] * W[n][tap = 2s + t2][c] (zero for the 26th tap), from the gather-packed fp32 weights [n][25][16]
 __global__ void conv2_pack_kernel(const float* __restrict__ wp, const float* __restrict__ scale, u16* __restrict__ wk) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -931,6 +1031,14 @@ extern "C" int svs_unet_forward_eval_bf16(const void* prepared_bf16, const float
     const long ldx = 2L * BCH[k - 1];
     u16* y = k == 6 ? e.c6 : e.cat[k] + BCH[k];
     const long ldy = k == 6 ? 512 : 2L * BCH[k];
+    if (k == 3 && svs_tune(SVS_TUNE_BF16_CONV3_WINDOW) != 0) {           // LDS-window form (SVS_BF16_CONV3_WINDOW=0: the GEMM form)
+      Conv3WinArgs c{x, ldx, B, e.h[2], e.w[2], (const u16*)(blob + L.w[2]), SH(2), 0.2f, y, ldy, e.h[3], e.w[3]};
+      const long tiles = (long)B * ((e.h[3] + 7) / 8) * ((e.w[3] + 15) / 16);
+      SVS_HIP(hipFuncSetAttribute((const void*)conv3_window_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CONV3_WIN_LDS));
+      hipLaunchKernelGGL(conv3_window_bf16_kernel, dim3((unsigned)(tiles < 256 ? tiles : 256)), dim3(256), CONV3_WIN_LDS, stream, c);
+      SVS_CHECK_LAUNCH("conv3_window_bf16");
+      continue;
+    }
     if ((rc = conv_bf16_run(BF_GATHER, x, ldx, B, e.h[k - 1], e.w[k - 1], BCH[k - 1], (const u16*)(blob + L.w[k - 1]), SH(k - 1), 0.2f, y, ldy, e.h[k], e.w[k],
                             BCH[k], e.scratch, e.scratch_bytes, stream))) return rc;
   }
