@@ -11,9 +11,9 @@
 //     that covers the whole K-tile (the fp32 form needs four 16x16x4 MFMAs per fragment);
 //   * eval-mode BatchNorm is folded: the per-channel scale goes into the bf16 weights, the shift and LeakyReLU / ReLU into
 //     the epilogue, which rounds to bf16 once (v_cvt_pk_bf16_f32) and stores 32-byte runs.
-// Level 1 is interleaved here ([decoder 16 | skip 16] = one 64-byte line per pixel): conv2 reads all 32 channels with zero
-// weights on the decoder half (which is therefore zero-filled at the start of a forward), so that no layer needs a 16-wide
-// K-tile.  Bound: HBM / launch at streaming batch sizes (bf16 MFMA peak ~2.5 PFLOP/s: 16x the fp32 rate).
+// Levels 2..5 are interleaved ([decoder half | skip half] per pixel); level 1 is PLANAR (a 16-channel decoder plane and a
+// 16-channel skip plane, 32 bytes per pixel each), so that conv1 / deconv5 write and conv2 reads whole HBM bursts instead of
+// 32 bytes of every 64.  Bound: HBM / launch at streaming batch sizes (bf16 MFMA peak ~2.5 PFLOP/s: 16x the fp32 rate).
 #include <type_traits>
 
 #include "internal.h"
@@ -430,8 +430,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_bf16_kernel(const float* 
   }
 }
 
-// conv1 (model.py:47-51): 1 -> 16 channels, 5x5, stride 2, fp32 input tile -> the skip half [16, 32) of the interleaved level-1
-// pixel.  One input channel gives no channel reduction, so the K of the MFMA is the 25 taps (padded to 32): first operand =
+// conv1 (model.py:47-51): 1 -> 16 channels, 5x5, stride 2, fp32 input tile -> the skip plane of level 1.  One input channel gives no channel reduction, so the K of the MFMA is the 25 taps (padded to 32): first operand =
 // weights [16 n][32 k], second = the im2col patch of 16 output pixels, gathered from an fp32 LDS window (lane (pixel, q) reads
 // the taps 8q .. 8q+7 of its patch).  The input keeps its fp32 information: x = hi + lo in two bf16 limbs, two MFMAs per 16
 // pixels against the same weights.  400 FMAs per pixel on the VALU (118 us at 216 tiles) become two MFMAs per 16 pixels; what
@@ -439,7 +438,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_bf16_kernel(const float* 
 struct Conv1Args { const float* x; int B, H, W; const u16* w1b; const float* shift; float slope; u16* y; long ldy; int Ho, Wo; };
 __global__ __launch_bounds__(256) void conv1_mfma_bf16_kernel(Conv1Args p) {
   constexpr int TH = 16, TW = 32, WR = 2 * TH + 3, WC = 2 * TW + 4;              // window rows; columns (67 used)
-  __shared__ float win[WR * WC];
+  __shared__ unsigned win[WR * WC];            // a sample as its two bf16 limbs, hi | lo << 16: split ONCE here, not once per tap that reads it
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lrow = lane & 15, q = lane >> 4;
   const int tiles_w = (p.Wo + TW - 1) / TW, tiles_h = (p.Ho + TH - 1) / TH;
   const int tile = blockIdx.x;
@@ -449,7 +448,9 @@ __global__ __launch_bounds__(256) void conv1_mfma_bf16_kernel(Conv1Args p) {
   for (int e = t; e < WR * WC; e += 256) {
     const int wr = e / WC, wc = e - wr * WC;
     const int ih = 2 * oh0 - 2 + wr, iw = 2 * ow0 - 2 + wc;
-    win[e] = ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) ? img[(long)ih * p.W + iw] : 0.f;
+    const float x = ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) ? img[(long)ih * p.W + iw] : 0.f;
+    const unsigned hi = to_bf16(x);
+    win[e] = hi | ((unsigned)to_bf16(x - __builtin_bit_cast(float, hi << 16)) << 16);
   }
   const bf16x8 fw = *(const bf16x8*)(p.w1b + lrow * 32 + q * 8);
   int off[8];
@@ -460,16 +461,15 @@ __global__ __launch_bounds__(256) void conv1_mfma_bf16_kernel(Conv1Args p) {
 #pragma unroll
   for (int g = 0; g < 8; ++g) {                                                  // wave: output rows 4 wave .. 4 wave + 3, two 16-pixel groups each
     const int ohl = 4 * wave + (g >> 1), owl = (g & 1) * 16 + lrow;
-    const float* const base = &win[(2 * ohl) * WC + 2 * owl];
-    float xv[8];
+    const unsigned* const base = &win[(2 * ohl) * WC + 2 * owl];
+    unsigned xv[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) xv[e] = base[off[e]];
     unsigned hi[4], lo[4];
 #pragma unroll
-    for (int h = 0; h < 4; ++h) {
-      hi[h] = (unsigned)to_bf16(xv[2 * h]) | ((unsigned)to_bf16(xv[2 * h + 1]) << 16);
-      const float r0 = xv[2 * h] - __builtin_bit_cast(float, hi[h] << 16), r1 = xv[2 * h + 1] - __builtin_bit_cast(float, hi[h] & 0xffff0000u);
-      lo[h] = (unsigned)to_bf16(r0) | ((unsigned)to_bf16(r1) << 16);
+    for (int h = 0; h < 4; ++h) {                                                // v_perm_b32: the two samples' hi (lo) halves side by side
+      hi[h] = __builtin_amdgcn_perm(xv[2 * h + 1], xv[2 * h], 0x05040100u);
+      lo[h] = __builtin_amdgcn_perm(xv[2 * h + 1], xv[2 * h], 0x07060302u);
     }
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw, __builtin_bit_cast(bf16x8, (uint4){lo[0], lo[1], lo[2], lo[3]}), acc, 0, 0, 0);
@@ -718,7 +718,10 @@ __global__ void conv2_pack_kernel(const float* __restrict__ wp, const float* __r
 // LDS (96-byte pixel pitch: the 16 pixels x 16 bytes of a ds_read_b128 group then fall on 64 distinct banks); every operand
 // fragment is one ds_read_b128.  Lanes of the columns 0..3 exchange with their pw-partner so that each writes one float4
 // of an output row.  Bound: HBM (32 ch x 2 B in, 4 x 4 B out per anchor).
-struct Deconv6Args { const u16* x; long ldx; int B, H, W; const u16* w2; const float* bias; float* y; int Ho, Wo; };
+struct Deconv6Args {
+  const u16* x; long ldx; int B, H, W; const u16* w2; const float* bias; float* y; int Ho, Wo;
+  long plane;        // elements from channel 0 to channel 16 of a pixel: 16 in an interleaved view, the plane distance in the planar level 1
+};
 __global__ __launch_bounds__(256) void deconv6_mfma_bf16_kernel(Deconv6Args p) {
   constexpr int TH = 8, TW = 16, WW = TW + 2, NPX = (TH + 2) * WW, PS = 48;     // PS: u16 per staged pixel
   __shared__ __attribute__((aligned(16))) u16 win[NPX * PS];
@@ -743,7 +746,8 @@ __global__ __launch_bounds__(256) void deconv6_mfma_bf16_kernel(Deconv6Args p) {
       const int lh = px / WW, lw = px - lh * WW;
       const int ih = fth0 - 1 + lh, iw = ftw0 - 1 + lw;
       stage[k] = make_uint4(0u, 0u, 0u, 0u);
-      if (px < NPX && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) stage[k] = *(const uint4*)(xb + ((long)ih * p.W + iw) * p.ldx + cq * 8);
+      if (px < NPX && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
+        stage[k] = *(const uint4*)(xb + ((long)ih * p.W + iw) * p.ldx + (cq & 1) * 8 + (cq >> 1) * p.plane);
     }
   };
   if ((int)blockIdx.x < ntiles) fetch_window(blockIdx.x);
@@ -1012,16 +1016,18 @@ extern "C" int svs_unet_forward_eval_bf16(const void* prepared_bf16, const float
   const Bf16Prepared L = bf16_prepared_layout();
   const char* blob = (const char*)prepared_bf16;
   auto SH = [&](int l) { return (const float*)(blob + L.shift[l]); };
-  // encoder (model.py:176-181).  Every level is one interleaved buffer [decoder half | skip half]; conv_k writes the skip half of
-  // level k and reads the skip half of level k - 1.  conv1 and conv2 have kernels of their own (1 and 16 input channels)
+  // encoder (model.py:176-181).  Levels 2..5 are one interleaved buffer [decoder half | skip half] each; conv_k writes the skip half
+  // of level k and reads the skip half of level k - 1.  Level 1 is PLANAR (decoder plane, then skip plane, 16 channels = 32 bytes per
+  // pixel each): interleaved, each producer wrote -- and conv2 read -- 32 bytes of every 64, i.e. half of every HBM burst
+  // (conv1 72 us for 170 MB at 216 tiles).  conv1 and conv2 have kernels of their own (1 and 16 input channels)
   {
-    Conv1Args c{mix, B, H, W, (const u16*)(blob + L.w1), SH(0), 0.2f, e.cat[1] + 16, 32L, e.h[1], e.w[1]};
+    Conv1Args c{mix, B, H, W, (const u16*)(blob + L.w1), SH(0), 0.2f, e.cat[1] + e.P[1] * 16, 16L, e.h[1], e.w[1]};
     const long tiles = (long)B * ((e.h[1] + 15) / 16) * ((e.w[1] + 31) / 32);
     hipLaunchKernelGGL(conv1_mfma_bf16_kernel, dim3((unsigned)tiles), dim3(256), 0, stream, c);
     SVS_CHECK_LAUNCH("conv1_mfma_bf16");
   }
   {
-    Conv2WinArgs c{e.cat[1] + 16, 32L, B, e.h[1], e.w[1], (const u16*)(blob + L.w2k), SH(1), 0.2f, e.cat[2] + 32, 64L, e.h[2], e.w[2]};
+    Conv2WinArgs c{e.cat[1] + e.P[1] * 16, 16L, B, e.h[1], e.w[1], (const u16*)(blob + L.w2k), SH(1), 0.2f, e.cat[2] + 32, 64L, e.h[2], e.w[2]};
     const long tiles = (long)B * ((e.h[2] + 7) / 8) * ((e.w[2] + 15) / 16);
     hipLaunchKernelGGL(conv2_window_bf16_kernel, dim3((unsigned)(tiles < 768 ? tiles : 768)), dim3(256), 0, stream, c);
     SVS_CHECK_LAUNCH("conv2_window_bf16");
@@ -1047,11 +1053,11 @@ extern "C" int svs_unet_forward_eval_bf16(const void* prepared_bf16, const float
     const int lin = 6 - j, lout = 5 - j;
     const u16* x = j == 0 ? e.c6 : e.cat[lin];
     if ((rc = conv_bf16_run(BF_PARITY, x, BDEC_C[j], B, e.h[lin], e.w[lin], BDEC_C[j], (const u16*)(blob + L.w[6 + j]), SH(6 + j), 0.f, e.cat[lout],
-                            2L * BCH[lout], e.h[lout], e.w[lout], BDEC_N[j], e.scratch, e.scratch_bytes, stream))) return rc;
+                            lout == 1 ? 16L : 2L * BCH[lout], e.h[lout], e.w[lout], BDEC_N[j], e.scratch, e.scratch_bytes, stream))) return rc;
   }
   // deconv6 + sigmoid (model.py:198-200)
   {
-    Deconv6Args d{e.cat[1], 32L, B, e.h[1], e.w[1], (const u16*)(blob + L.w6), (const float*)(blob + L.bias6), mask, H, W};
+    Deconv6Args d{e.cat[1], 16L, B, e.h[1], e.w[1], (const u16*)(blob + L.w6), (const float*)(blob + L.bias6), mask, H, W, e.P[1] * 16};
     const long tiles = (long)B * ((e.h[1] + 7) / 8) * ((e.w[1] + 15) / 16);
     hipLaunchKernelGGL(deconv6_mfma_bf16_kernel, dim3((unsigned)(tiles < 2048 ? tiles : 2048)), dim3(256), 0, stream, d);
     SVS_CHECK_LAUNCH("deconv6_mfma_bf16");
