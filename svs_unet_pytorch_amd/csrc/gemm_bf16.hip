@@ -735,19 +735,31 @@ __global__ __launch_bounds__(256) void deconv6_mfma_bf16_kernel(Deconv6Args p) {
 #pragma unroll
   for (int pos = 0; pos < 9; ++pos) fb[pos] = *(const bf16x8*)(p.w2 + (pos * 16 + lrow) * 32 + q * 8);
   const float bias = p.bias[0];
-  const int ph = (lrow >> 1) & 1, pw = lrow & 1;
+  // Window staging with as few VALU instructions per tile as possible (the kernel is VALU-bound: 423 per tile and wave before, of
+  // which the index arithmetic of the 3 staged pieces per thread was ~100): a thread's pieces are the same window positions in
+  // every tile, so (row, column, byte offset relative to the tile's first window pixel, LDS address) are computed ONCE; per tile
+  // only the bounds test remains, and the tile's position is a scalar offset of a buffer load (out of the image: offset past
+  // num_records, which reads as zeros).
+  constexpr unsigned OOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x - ((long)p.W + 1) * p.ldx), 0, OOB, 0x00020000);
+  int s_lh[NST], s_lw[NST]; unsigned s_rel[NST]; u16* s_dst[NST];
+#pragma unroll
+  for (int k = 0; k < NST; ++k) {
+    const int e = t + k * 256, px = e >> 2, cq = e & 3;
+    s_lh[k] = px / WW; s_lw[k] = px - s_lh[k] * WW;
+    if (px >= NPX) s_lh[k] = -(1 << 20);                          // never inside the image
+    s_rel[k] = (unsigned)((((long)s_lh[k] * p.W + s_lw[k]) * p.ldx + (cq & 1) * 8 + (cq >> 1) * p.plane) * 2);
+    s_dst[k] = &win[(px < NPX ? px : 0) * PS + cq * 8];
+  }
   uint4 stage[NST];
   auto fetch_window = [&](int tile) __attribute__((always_inline)) {
     const int ftw0 = (tile % tiles_w) * TW, fth0 = ((tile / tiles_w) % tiles_h) * TH;
-    const u16* const xb = p.x + (long)(tile / (tiles_w * tiles_h)) * p.H * p.W * p.ldx;
+    const int fb_ = tile / (tiles_w * tiles_h);
+    const int soff = __builtin_amdgcn_readfirstlane((int)((((long)fb_ * p.H + fth0) * p.W + ftw0) * p.ldx * 2));
 #pragma unroll
     for (int k = 0; k < NST; ++k) {
-      const int e = t + k * 256, px = e >> 2, cq = e & 3;
-      const int lh = px / WW, lw = px - lh * WW;
-      const int ih = fth0 - 1 + lh, iw = ftw0 - 1 + lw;
-      stage[k] = make_uint4(0u, 0u, 0u, 0u);
-      if (px < NPX && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
-        stage[k] = *(const uint4*)(xb + ((long)ih * p.W + iw) * p.ldx + (cq & 1) * 8 + (cq >> 1) * p.plane);
+      const bool ok = (unsigned)(fth0 - 1 + s_lh[k]) < (unsigned)p.H && (unsigned)(ftw0 - 1 + s_lw[k]) < (unsigned)p.W;
+      stage[k] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(ok ? s_rel[k] : OOB), soff, 0));
     }
   };
   if ((int)blockIdx.x < ntiles) fetch_window(blockIdx.x);
@@ -756,10 +768,8 @@ __global__ __launch_bounds__(256) void deconv6_mfma_bf16_kernel(Deconv6Args p) {
     const long b = tile / (tiles_w * tiles_h);
     __syncthreads();                                               // the previous tile's readers are done
 #pragma unroll
-    for (int k = 0; k < NST; ++k) {
-      const int e = t + k * 256, px = e >> 2, cq = e & 3;
-      if (px < NPX) *(uint4*)(&win[px * PS + cq * 8]) = stage[k];
-    }
+    for (int k = 0; k < NST; ++k)
+      if (t + k * 256 < NPX * 4) *(uint4*)s_dst[k] = stage[k];
     if (tile + (int)gridDim.x < ntiles) fetch_window(tile + gridDim.x);
     __syncthreads();
 #pragma unroll
@@ -772,26 +782,21 @@ __global__ __launch_bounds__(256) void deconv6_mfma_bf16_kernel(Deconv6Args p) {
         const bf16x8 fa = *(const bf16x8*)(&win[((ah + dh) * WW + lrow + dw) * PS + q * 8]);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[pos], acc, 0, 0, 0);
       }
-      // C map: column lrow (= parity for lrow < 4), rows q*4 + r = anchors tw0 + q*4 + r
-      float own[4], oth[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        own[r] = 1.f / (1.f + __expf(-(acc[r] + bias)));
-        oth[r] = __shfl_xor(own[r], 1, 64);
-      }
-      const int oh = 2 * (th0 + ah) + ph;
-      if (lrow >= 4 || th0 + ah >= p.H || oh >= p.Ho) continue;
-      // pw = 0 writes the outputs of anchors q*4, q*4+1 (4 columns), pw = 1 those of anchors q*4+2, q*4+3
-      const int ow0 = 2 * (tw0 + q * 4) + 4 * pw;
-      const float v0 = pw ? oth[2] : own[0], v1 = pw ? own[2] : oth[0], v2 = pw ? oth[3] : own[1], v3 = pw ? own[3] : oth[1];
-      float* dst = p.y + (b * p.Ho + oh) * p.Wo + ow0;
-      if ((p.Wo & 3) == 0 && ow0 + 3 < p.Wo) *(f32x4*)dst = (f32x4){v0, v1, v2, v3};
-      else {
-        if (ow0 < p.Wo) dst[0] = v0;
-        if (ow0 + 1 < p.Wo) dst[1] = v1;
-        if (ow0 + 2 < p.Wo) dst[2] = v2;
-        if (ow0 + 3 < p.Wo) dst[3] = v3;
-      }
+      // C map: column lrow (= parity for lrow < 4), rows q*4 + r = anchors tw0 + q*4 + r.  Only the columns 0..3 carry outputs:
+      // register r of lane (q, c < 4) moves to lane (q, c + 4 r) (DPP row_shr inside the 16-lane row, written through a bank
+      // mask), so that every lane holds ONE output -- anchor q*4 + (lrow >> 2), parity lrow & 3 -- and evaluates one sigmoid
+      // instead of four; a row of 32 outputs (16 anchors x 2 column parities) then leaves as 4-byte stores of 32 adjacent lanes.
+      // (the four registers go through opaque asm copies first: hipcc of ROCm 7.2 otherwise reads accumulator register 0 for all
+      // four DPP sources -- v_accvgpr_read a0 twice, no a1..a3 -- and the outputs are wrong)
+      float v = acc[0], a1 = acc[1], a2 = acc[2], a3 = acc[3];
+      asm volatile("" : "+v"(v), "+v"(a1), "+v"(a2), "+v"(a3));
+      v = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, a1), 0x114, 0xF, 0x2, false));   // row_shr:4  -> lanes 4..7
+      v = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, a2), 0x118, 0xF, 0x4, false));   // row_shr:8  -> lanes 8..11
+      v = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, a3), 0x11C, 0xF, 0x8, false));   // row_shr:12 -> lanes 12..15
+      v = 1.f / (1.f + __expf(-(v + bias)));
+      const int par = lrow & 3, an = q * 4 + (lrow >> 2);
+      const int oh = 2 * (th0 + ah) + (par >> 1), ow = 2 * (tw0 + an) + (par & 1);
+      if (th0 + ah < p.H && tw0 + an < p.W && oh < p.Ho && ow < p.Wo) p.y[(b * p.Ho + oh) * p.Wo + ow] = v;
     }
   }
 }
