@@ -438,51 +438,81 @@ __global__ __launch_bounds__(256) void splitk_epilogue_bf16_kernel(const float* 
 struct Conv1Args { const float* x; int B, H, W; const u16* w1b; const float* shift; float slope; u16* y; long ldy; int Ho, Wo; };
 __global__ __launch_bounds__(256) void conv1_mfma_bf16_kernel(Conv1Args p) {
   constexpr int TH = 16, TW = 32, WR = 2 * TH + 3, WC = 2 * TW + 4;              // window rows; columns (67 used)
+  constexpr int NST = (WR * WC + 255) / 256;                                     // window samples per thread (10)
+  constexpr unsigned OOB = 0x80000000u;
   __shared__ unsigned win[WR * WC];            // a sample as its two bf16 limbs, hi | lo << 16: split ONCE here, not once per tap that reads it
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lrow = lane & 15, q = lane >> 4;
   const int tiles_w = (p.Wo + TW - 1) / TW, tiles_h = (p.Ho + TH - 1) / TH;
-  const int tile = blockIdx.x;
-  const int ow0 = (tile % tiles_w) * TW, oh0 = ((tile / tiles_w) % tiles_h) * TH;
-  const long b = tile / (tiles_w * tiles_h);
-  const float* const img = p.x + b * p.H * p.W;
-  for (int e = t; e < WR * WC; e += 256) {
-    const int wr = e / WC, wc = e - wr * WC;
-    const int ih = 2 * oh0 - 2 + wr, iw = 2 * ow0 - 2 + wc;
-    const float x = ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) ? img[(long)ih * p.W + iw] : 0.f;
-    const unsigned hi = to_bf16(x);
-    win[e] = hi | ((unsigned)to_bf16(x - __builtin_bit_cast(float, hi << 16)) << 16);
+  const int ntiles = p.B * tiles_h * tiles_w;
+  // Persistent blocks with the NEXT tile's window in flight (registers) while the current tile is computed: as one block per tile
+  // the kernel was a chain of load latency -> barrier -> gather -> store per block (59 us for 170 MB at 216 tiles).  A thread's
+  // samples are the same window positions in every tile: row, column and byte offset are computed once, the tile's position
+  // is the scalar offset of a buffer load, a sample outside the image is pointed past num_records and reads as zero.
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x - (2L * p.W + 2)), 0, OOB, 0x00020000);
+  int s_wr[NST], s_wc[NST]; unsigned s_rel[NST];
+#pragma unroll
+  for (int k = 0; k < NST; ++k) {
+    const int e = t + k * 256;
+    s_wr[k] = e / WC; s_wc[k] = e - s_wr[k] * WC;
+    if (e >= WR * WC) s_wr[k] = -(1 << 20);
+    s_rel[k] = (unsigned)(((long)s_wr[k] * p.W + s_wc[k]) * 4);
   }
+  float stage[NST];
+  auto fetch_window = [&](int tile) __attribute__((always_inline)) {
+    const int fow0 = (tile % tiles_w) * TW, foh0 = ((tile / tiles_w) % tiles_h) * TH;
+    const int fb_ = tile / (tiles_w * tiles_h);
+    const int soff = __builtin_amdgcn_readfirstlane((int)((((long)fb_ * p.H + 2 * foh0) * p.W + 2 * fow0) * 4));
+#pragma unroll
+    for (int k = 0; k < NST; ++k) {
+      const bool ok = (unsigned)(2 * foh0 - 2 + s_wr[k]) < (unsigned)p.H && (unsigned)(2 * fow0 - 2 + s_wc[k]) < (unsigned)p.W;
+      stage[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (int)(ok ? s_rel[k] : OOB), soff, 0));
+    }
+  };
   const bf16x8 fw = *(const bf16x8*)(p.w1b + lrow * 32 + q * 8);
   int off[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { const int k = q * 8 + e < 25 ? q * 8 + e : 24; off[e] = (k / 5) * WC + (k % 5); }   // (taps 25..31: zero weights)
   const f32x4 sh = *(const f32x4*)(p.shift + q * 4);
-  __syncthreads();
+  if ((int)blockIdx.x < ntiles) fetch_window(blockIdx.x);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int ow0 = (tile % tiles_w) * TW, oh0 = ((tile / tiles_w) % tiles_h) * TH;
+    const long b = tile / (tiles_w * tiles_h);
+    __syncthreads();                                                               // the previous tile's readers are done
 #pragma unroll
-  for (int g = 0; g < 8; ++g) {                                                  // wave: output rows 4 wave .. 4 wave + 3, two 16-pixel groups each
-    const int ohl = 4 * wave + (g >> 1), owl = (g & 1) * 16 + lrow;
-    const unsigned* const base = &win[(2 * ohl) * WC + 2 * owl];
-    unsigned xv[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) xv[e] = base[off[e]];
-    unsigned hi[4], lo[4];
-#pragma unroll
-    for (int h = 0; h < 4; ++h) {                                                // v_perm_b32: the two samples' hi (lo) halves side by side
-      hi[h] = __builtin_amdgcn_perm(xv[2 * h + 1], xv[2 * h], 0x05040100u);
-      lo[h] = __builtin_amdgcn_perm(xv[2 * h + 1], xv[2 * h], 0x07060302u);
+    for (int k = 0; k < NST; ++k) {
+      const int e = t + k * 256;
+      const float x = stage[k];
+      const unsigned hi = to_bf16(x);
+      if (e < WR * WC) win[e] = hi | ((unsigned)to_bf16(x - __builtin_bit_cast(float, hi << 16)) << 16);
     }
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw, __builtin_bit_cast(bf16x8, (uint4){lo[0], lo[1], lo[2], lo[3]}), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw, __builtin_bit_cast(bf16x8, (uint4){hi[0], hi[1], hi[2], hi[3]}), acc, 0, 0, 0);
-    const int oh = oh0 + ohl, ow = ow0 + owl;
-    if (oh >= p.Ho || ow >= p.Wo) continue;
-    float v[4];
+    if (tile + (int)gridDim.x < ntiles) fetch_window(tile + gridDim.x);
+    __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { const float u = acc[r] + sh[r]; v[r] = u > 0.f ? u : u * p.slope; }
-    uint2 o;
-    o.x = (unsigned)to_bf16(v[0]) | ((unsigned)to_bf16(v[1]) << 16);
-    o.y = (unsigned)to_bf16(v[2]) | ((unsigned)to_bf16(v[3]) << 16);
-    *(uint2*)(p.y + ((b * p.Ho + oh) * p.Wo + ow) * p.ldy + q * 4) = o;
+    for (int g = 0; g < 8; ++g) {                                                  // wave: output rows 4 wave .. 4 wave + 3, two 16-pixel groups each
+      const int ohl = 4 * wave + (g >> 1), owl = (g & 1) * 16 + lrow;
+      const unsigned* const base = &win[(2 * ohl) * WC + 2 * owl];
+      unsigned xv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xv[e] = base[off[e]];
+      unsigned hi[4], lo[4];
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {                                                // v_perm_b32: the two samples' hi (lo) halves side by side
+        hi[h] = __builtin_amdgcn_perm(xv[2 * h + 1], xv[2 * h], 0x05040100u);
+        lo[h] = __builtin_amdgcn_perm(xv[2 * h + 1], xv[2 * h], 0x07060302u);
+      }
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw, __builtin_bit_cast(bf16x8, (uint4){lo[0], lo[1], lo[2], lo[3]}), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw, __builtin_bit_cast(bf16x8, (uint4){hi[0], hi[1], hi[2], hi[3]}), acc, 0, 0, 0);
+      const int oh = oh0 + ohl, ow = ow0 + owl;
+      if (oh >= p.Ho || ow >= p.Wo) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const float u = acc[r] + sh[r]; v[r] = u > 0.f ? u : u * p.slope; }
+      uint2 o;
+      o.x = (unsigned)to_bf16(v[0]) | ((unsigned)to_bf16(v[1]) << 16);
+      o.y = (unsigned)to_bf16(v[2]) | ((unsigned)to_bf16(v[3]) << 16);
+      *(uint2*)(p.y + ((b * p.Ho + oh) * p.Wo + ow) * p.ldy + q * 4) = o;
+    }
   }
 }
 // w1b[n][k]: scale[n] * W[n][tap k] for k < 25, zero for the padding taps
@@ -1017,6 +1047,9 @@ extern "C" int svs_unet_forward_eval_bf16(const void* prepared_bf16, const float
   int rc = bf16_ws_layout(B, H, W, ws, e);
   if (rc) return rc;
   SVS_REQUIRE(prepared_bf16 && mix && mask && svs_aligned16(mix) && svs_aligned16(mask), "svs_unet_forward_eval_bf16: bad pointers");
+  // conv1 / deconv6 address the input tiles and the two level-1 planes with 32-bit byte offsets (buffer loads)
+  SVS_REQUIRE(((long)B * H * W + 4L * W) * 4 < (1L << 31) && (e.P[1] * 32 + 4L * e.w[1] * 16) * 2 < (1L << 31),
+              "svs_unet_forward_eval_bf16: %d tiles of %dx%d need 64-bit offsets; split the batch", B, H, W);
   if (!ws || ws_bytes < e.total || !svs_aligned16(ws)) { svs_set_error("svs_unet_forward_eval_bf16: workspace too small (%zu < %zu)", ws_bytes, e.total); return SVS_ERR_WORKSPACE; }
   const Bf16Prepared L = bf16_prepared_layout();
   const char* blob = (const char*)prepared_bf16;
@@ -1028,7 +1061,7 @@ extern "C" int svs_unet_forward_eval_bf16(const void* prepared_bf16, const float
   {
     Conv1Args c{mix, B, H, W, (const u16*)(blob + L.w1), SH(0), 0.2f, e.cat[1] + e.P[1] * 16, 16L, e.h[1], e.w[1]};
     const long tiles = (long)B * ((e.h[1] + 15) / 16) * ((e.w[1] + 31) / 32);
-    hipLaunchKernelGGL(conv1_mfma_bf16_kernel, dim3((unsigned)tiles), dim3(256), 0, stream, c);
+    hipLaunchKernelGGL(conv1_mfma_bf16_kernel, dim3((unsigned)(tiles < 2048 ? tiles : 2048)), dim3(256), 0, stream, c);      // persistent: 8 blocks per CU
     SVS_CHECK_LAUNCH("conv1_mfma_bf16");
   }
   {
