@@ -238,16 +238,20 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_kernel(ConvBf16Args p) {
 // reads its A fragments at base + compile-time offset.  Weight fragments come from global memory (shared by all blocks:
 // L2-resident), one tap ahead.  Same structure as parity_window_kernel of gemm_conv.hip; one MFMA covers 32 channels.
 // ------------------------------------------------------------------------------------------------
-template <int C, int TN>
+// TW = 16: tiles of 8 x 16 anchors (a 16-anchor MFMA row tile is one anchor row); TW = 8: tiles of 16 x 8 anchors (a row tile is two
+// anchor rows of 8) for deconv3, whose input is 32 x 8 anchors per image.  The window and the weight buffers live in dynamic LDS
+// (deconv3: 180 pixels x 528 bytes + 2 x 64 x 528 bytes = 159 KB, one block per CU).
+template <int C, int TN, int TW = 16>
 __global__ __launch_bounds__(256) void parity_window_bf16_kernel(ConvBf16Args p) {
-  constexpr int TH = 8, TW = 16, TM = 2;
+  constexpr int TH = 128 / TW, TM = 2, RPT = 16 / TW;            // RPT: anchor rows per 16-anchor row tile
   constexpr int LPB = C * 2 + 16;                               // bytes per staged pixel
   constexpr int WW = TW + 2, NPX = (TH + 2) * WW;
   constexpr int CQ = C / 8, CC = C / 32;
   constexpr int NST = (NPX * CQ + 255) / 256;
   constexpr unsigned OOB = 0x80000000u;
   constexpr int POFF[4] = {0, 9, 15, 21};
-  __shared__ __attribute__((aligned(16))) unsigned char win[NPX * LPB];
+  extern __shared__ __attribute__((aligned(16))) unsigned char pw_smem[];
+  unsigned char* const win = pw_smem;                            // [NPX * LPB]
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int lrow = lane & 15, q = lane >> 4;
   const int tiles_w = (p.W + TW - 1) / TW, tiles_h = (p.H + TH - 1) / TH;
@@ -287,7 +291,7 @@ __global__ __launch_bounds__(256) void parity_window_bf16_kernel(ConvBf16Args p)
     }
   };
   // A fragment of row tile i: anchor (2 wave + i, lrow) at window coordinate (+1, +1), 16-byte chunk q of a 32-channel step
-  const unsigned char* abase = &win[((2 * wave + 1) * WW + lrow + 1) * LPB + q * 16];
+  const unsigned char* abase = &win[((RPT * 2 * wave + lrow / TW + 1) * WW + lrow % TW + 1) * LPB + q * 16];
   // Weights of one tap ([n][C] bf16, N * C * 2 bytes) are brought into LDS ONCE per block and tap (double-buffered, one
   // barrier per tap) and every wave reads its B fragments from there: fetched per wave from L2 they were 4x the traffic
   // (1.4 GB per launch at 216 tiles -- the L2, not the MFMA, set the kernel's time).
@@ -302,10 +306,11 @@ __global__ __launch_bounds__(256) void parity_window_bf16_kernel(ConvBf16Args p)
   // per wave and tap a barrier per tap cost more than the MFMAs); deconv4's 205 KB go through two per-tap buffers
   constexpr bool WALL = WSWZ;
   constexpr int NBUF = WALL ? 25 : 2;
-  __shared__ __attribute__((aligned(16))) unsigned char wts[NBUF][N * WPB];
+  unsigned char (*const wts)[N * WPB] = (unsigned char (*)[N * WPB])(pw_smem + NPX * LPB);      // [NBUF][N * WPB]
+  static_assert((NPX * LPB) % 16 == 0, "weight buffers 16-byte aligned");
   // per-tap weights (deconv4): DEPTH register sets, so that the request for tap s + DEPTH (wrapping into the next tile: the
   // weights do not depend on the tile) is in flight during DEPTH taps -- with one tap ahead every tap waited an L2 round trip
-  constexpr int DEPTH = WALL ? 1 : 5;
+  constexpr int DEPTH = WALL ? 1 : 5;                           // (must divide 25: tap s lives in set s % DEPTH across the tile boundary)
   f32x4 wreg[DEPTH][NWL];
   auto fetch_w = [&](auto sc, auto setc) __attribute__((always_inline)) {         // global -> register set: weights of step sc
     constexpr int s_ = decltype(sc)::value;
@@ -340,7 +345,7 @@ __global__ __launch_bounds__(256) void parity_window_bf16_kernel(ConvBf16Args p)
     for (int cc = 0; cc < CC; ++cc) {
       bf16x8 fa[TM], fb[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fa[i] = __builtin_bit_cast(bf16x8, *(const f32x4*)(abase + aoff + i * WW * LPB + cc * 64));
+      for (int i = 0; i < TM; ++i) fa[i] = __builtin_bit_cast(bf16x8, *(const f32x4*)(abase + aoff + i * RPT * WW * LPB + cc * 64));
 #pragma unroll
       for (int j = 0; j < TN; ++j) fb[j] = __builtin_bit_cast(bf16x8, *(const f32x4*)(wb + j * 16 * WPB + wpos(lrow, cc * 4 + q) * 16));
 #pragma unroll
@@ -361,8 +366,8 @@ __global__ __launch_bounds__(256) void parity_window_bf16_kernel(ConvBf16Args p)
     const int ph = par >> 1, pw = par & 1;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      const int a = th0 + 2 * wave + i, oh = 2 * a + ph;
-      const int c = tw0 + lrow, ow = 2 * c + pw;
+      const int a = th0 + RPT * (2 * wave + i) + lrow / TW, oh = 2 * a + ph;
+      const int c = tw0 + lrow % TW, ow = 2 * c + pw;
       if (a >= p.H || oh >= p.Ho || c >= p.W || ow >= p.Wo) continue;
       u16* const dst = p.y + ((b * p.Ho + oh) * p.Wo + ow) * p.ldy + q * 4;
 #pragma unroll
@@ -385,11 +390,15 @@ __global__ __launch_bounds__(256) void parity_window_bf16_kernel(ConvBf16Args p)
     stash_w(0, I0{});
   }
   int gstep = 0;                               // taps done so far (all tiles): its parity is the weight buffer of the current tap
-  if ((int)blockIdx.x < ntiles) fetch_window(blockIdx.x);
+  // (deconv3: 23 pieces of window per thread -- no registers left to hold the next tile's beside five weight sets; a block has
+  // at most two tiles there, the window is fetched at the start of each)
+  constexpr bool PREFETCH = NST <= 12;
+  if (PREFETCH && (int)blockIdx.x < ntiles) fetch_window(blockIdx.x);
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     if constexpr (WALL) __syncthreads();       // the previous tile's readers are done with the window (per-tap kernels: the tap barrier)
+    if constexpr (!PREFETCH) fetch_window(tile);
     commit_window(tile);
-    if (tile + (int)gridDim.x < ntiles) fetch_window(tile + gridDim.x);
+    if (PREFETCH && tile + (int)gridDim.x < ntiles) fetch_window(tile + gridDim.x);
     __syncthreads();
     bf_static_for<25>([&](auto sc) {
       constexpr int s_ = decltype(sc)::value;
@@ -924,12 +933,37 @@ static int conv_bf16_run(int mode, const u16* x, long ldx, int B, int H, int W, 
   ConvBf16Args a{x, ldx, B, H, W, C, wp, shift, slope, y, ldy, Ho, Wo, N, pl.ksplit, nullptr};
   // shallow decoder layers: LDS-window kernel (whenever its tiles fill the chip)
   const long wtiles = (long)B * ((H + 7) / 8) * ((W + 15) / 16);
+  // LDS of parity_window_bf16_kernel<C, N / 16, TW>: window + weight buffers (all 25 taps when they fit 60 KB unpadded, else two)
+  auto pw_lds = [](int C_, int N_, int TW_) -> size_t {
+    const size_t win = (size_t)(128 / TW_ + 2) * (TW_ + 2) * (C_ * 2 + 16);
+    const bool wall = 25L * N_ * (C_ * 2 + 16) <= 60 * 1024;
+    return win + (wall ? (size_t)25 * N_ * C_ * 2 : (size_t)2 * N_ * (C_ * 2 + 16));
+  };
   if (mode == BF_PARITY && ((C == 128 && N == 32) || (C == 64 && N == 16)) && H >= 8 && W >= 16 && wtiles >= 128 &&
       (long)H * W * ldx * 2 < (1L << 31) && svs_tune(SVS_TUNE_CONV_WINDOW) != 0) {
     a.ksplit = 1;
     const unsigned wgrid = (unsigned)(wtiles < 512 ? wtiles : 512);      // persistent: two blocks per CU
-    if (C == 128) hipLaunchKernelGGL((parity_window_bf16_kernel<128, 2>), dim3(wgrid), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((parity_window_bf16_kernel<64, 1>), dim3(wgrid), dim3(256), 0, stream, a);
+    const size_t lds = pw_lds(C, N, 16);
+    if (C == 128) {
+      SVS_HIP(hipFuncSetAttribute((const void*)parity_window_bf16_kernel<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL((parity_window_bf16_kernel<128, 2>), dim3(wgrid), dim3(256), lds, stream, a);
+    } else {
+      SVS_HIP(hipFuncSetAttribute((const void*)parity_window_bf16_kernel<64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL((parity_window_bf16_kernel<64, 1>), dim3(wgrid), dim3(256), lds, stream, a);
+    }
+    SVS_CHECK_LAUNCH("parity_window_bf16");
+    return SVS_OK;
+  }
+  // deconv3 (256 -> 64 channels on 32 x 8 anchors): the same kernel on 16 x 8 tiles.  In the GEMM form 1 GB goes from L2 to LDS
+  // per launch at 216 tiles (every anchor's 512 bytes once per tap, the 128 x 64 tile re-reading them for 64 channels only):
+  // 106 us; here the window is staged once and only the weights (819 KB per tile) stream.  SVS_BF16_DECONV3_WINDOW=0: GEMM form.
+  const long wtiles8 = (long)B * ((H + 15) / 16) * ((W + 7) / 8);
+  if (mode == BF_PARITY && C == 256 && N == 64 && W <= 8 && wtiles8 >= 128 && (long)H * W * ldx * 2 < (1L << 31) &&
+      svs_tune(SVS_TUNE_CONV_WINDOW) != 0 && svs_tune(SVS_TUNE_BF16_DECONV3_WINDOW) != 0) {
+    a.ksplit = 1;
+    const size_t lds = pw_lds(256, 64, 8);
+    SVS_HIP(hipFuncSetAttribute((const void*)parity_window_bf16_kernel<256, 4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((parity_window_bf16_kernel<256, 4, 8>), dim3((unsigned)(wtiles8 < 256 ? wtiles8 : 256)), dim3(256), lds, stream, a);
     SVS_CHECK_LAUNCH("parity_window_bf16");
     return SVS_OK;
   }

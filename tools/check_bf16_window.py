@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""conv3 of the bf16 network: LDS-window form (default) against the GEMM form (SVS_BF16_CONV3_WINDOW=0) on the whole forward, several
-tile geometries (both accumulate in fp32 in different orders and round to bf16 once: the masks agree to a few bf16 ulps of the
+"""conv3 / deconv3 of the bf16 network: LDS-window form (default) against the GEMM form (SVS_BF16_CONV3_WINDOW=0 /
+SVS_BF16_DECONV3_WINDOW=0) on the whole forward, several tile geometries (both accumulate in fp32 in different orders and round to bf16 once: the masks agree to a few bf16 ulps of the
 intermediate activations), and the time of a 216-tile forward either way."""
 import os
 import sys
@@ -17,13 +17,14 @@ model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in synth.closed
 model.to("cuda").eval()
 model.eval_precision = "bf16"
 bad = 0
-for shape in ((4, 1, 512, 128), (3, 1, 513, 128), (2, 1, 512, 100), (1, 1, 300, 77), (16, 1, 512, 128)):
+SWITCH = sys.argv[1] if len(sys.argv) > 1 else "BF16_CONV3_WINDOW"
+for shape in ((4, 1, 512, 128), (3, 1, 513, 128), (2, 1, 512, 100), (1, 1, 300, 77), (16, 1, 512, 128), (130, 1, 512, 128)):
     torch.manual_seed(1)
     x = torch.rand(shape, device="cuda")
     with torch.no_grad():
-        _lib.tuning("BF16_CONV3_WINDOW", 0)
+        _lib.tuning(SWITCH, 0)
         ref = model(x).clone()
-        _lib.tuning("BF16_CONV3_WINDOW", -1)
+        _lib.tuning(SWITCH, -1)
         out = model(x).clone()
         model.eval_precision = "fp32"
         f32 = model(x).clone()
@@ -34,7 +35,7 @@ for shape in ((4, 1, 512, 128), (3, 1, 513, 128), (2, 1, 512, 100), (1, 1, 300, 
         bad += 1
 x = torch.rand((216, 1, 512, 128), device="cuda")
 for val in (0, -1, 0, -1):
-    _lib.tuning("BF16_CONV3_WINDOW", val)
+    _lib.tuning(SWITCH, val)
     with torch.no_grad():
         for _ in range(3):
             model(x)
@@ -45,6 +46,6 @@ for val in (0, -1, 0, -1):
             model(x)
         b.record()
         torch.cuda.synchronize()
-    print(f"BF16_CONV3_WINDOW={val}: 216-tile bf16 forward {a.elapsed_time(b) / 20:.4f} ms")
+    print(f"{SWITCH}={val}: 216-tile bf16 forward {a.elapsed_time(b) / 20:.4f} ms")
 print("OK" if not bad else "FAILED")
 sys.exit(1 if bad else 0)
