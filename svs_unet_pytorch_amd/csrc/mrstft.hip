@@ -39,6 +39,7 @@ static const int MR_WIN[MR_NRES] = {600, 1200, 240};
 template <int N> struct MrCfg {
   static constexpr int WAVES = 8;
   static constexpr int WIN = (N == 2048) ? 1200 : (N == 1024) ? 600 : 240;      // = MR_WIN of this n_fft (checked on the host)
+  static constexpr int HOP = (N == 2048) ? 240 : (N == 1024) ? 120 : 50;          // = MR_HOP of this n_fft (checked on the host)
   static constexpr int OFF = (N - WIN) / 2, NJ = (WIN + 63) / 64;
 };
 static int mr_waves(int n) { (void)n; return 8; }
@@ -236,19 +237,20 @@ __global__ __launch_bounds__(64 * MrCfg<N>::WAVES) void mr_pass_kernel(MrArgs p)
   // ---- overlap-add of the block's WV frames (local frame f = its wave) over their common support: local position i = f hop + j,
   // j = index inside the window.  A thread owns positions tid, tid + 64 WV, ... and adds the <= ceil(win / hop) frames that
   // cover each in ascending f: a fixed order.
-  constexpr int WIN = MrCfg<N>::WIN, off = MrCfg<N>::OFF;
-  const int t0 = blockIdx.x * WV, SL = (WV - 1) * p.hop + WIN;
+  constexpr int WIN = MrCfg<N>::WIN, off = MrCfg<N>::OFF, HOP = MrCfg<N>::HOP;      // (compile-time hop: the divisions below are multiplications)
+  const int t0 = blockIdx.x * WV;
+  constexpr int SL = (WV - 1) * HOP + WIN;
   float2* const seg = (float2*)p.frames + ((long)b * gridDim.x + blockIdx.x) * SL;
   const float inv_win = 1.0f / (float)WIN;
   for (int i = tid; i < SL; i += 64 * WV) {
-    int f_hi = (int)((unsigned)i / (unsigned)p.hop);
+    int f_hi = (int)((unsigned)i / (unsigned)HOP);
     if (f_hi > WV - 1) f_hi = WV - 1;
     if (t0 + f_hi > p.F - 1) f_hi = p.F - 1 - t0;
     int f_lo = i - (WIN - 1);
-    f_lo = f_lo <= 0 ? 0 : (int)((unsigned)(f_lo + p.hop - 1) / (unsigned)p.hop);
+    f_lo = f_lo <= 0 ? 0 : (int)((unsigned)(f_lo + HOP - 1) / (unsigned)HOP);
     float2 s = float2{0.f, 0.f};
     for (int f = f_lo; f <= f_hi; ++f) {
-      const int j = i - f * p.hop;
+      const int j = i - f * HOP;
       const float2 z = fbuf[f * BUF + fft_pad(j + off)];
       const float w = mr_window_at(j, inv_win);
       s.x += z.x * w;
@@ -265,11 +267,14 @@ struct MrOlaArgs {
 // contributions of padded position q (= p + N/2) of one resolution to its sample: in "frame-window" coordinates u = q - off
 // (= hop t + j for a frame t and a window index j) the sample takes the block segments that cover u -- segment k spans
 // [8 hop k, 8 hop k + 7 hop + win) -- at most two of them, the earlier block first: a fixed order.  (sc, log) pairs.
-__device__ __forceinline__ float2 mr_gather(const float2* sg, int N, int win, int hop, int nseg, int q) {
+// (n_fft, window, hop are template arguments: the division by the segment span is then a multiplication -- with run-time values the
+// three resolutions' gathers were ~45 % of this kernel's instructions in divisions)
+template <int N, int win, int hop>
+__device__ __forceinline__ float2 mr_gather(const float2* sg, int nseg, int q) {
   const int u = q - (N - win) / 2;                        // (32-bit throughout: L + n_fft < 2^31 is checked on the host)
   float2 s = float2{0.f, 0.f};
   if (u < 0) return s;
-  const int span = 8 * hop, SL = 7 * hop + win;
+  constexpr int span = 8 * hop, SL = 7 * hop + win;
   const int k = (int)((unsigned)u / (unsigned)span);
   const int r = u - k * span;                             // position inside segment k
   if (k >= 1 && k - 1 < nseg && r + span < SL) { const float2 v = sg[(long)(k - 1) * SL + r + span]; s.x += v.x; s.y += v.y; }   // the previous segment's tail
@@ -283,17 +288,20 @@ __global__ __launch_bounds__(256) void mr_ola_kernel(MrOlaArgs a) {
   if (blockIdx.x == 0 && b == 0 && threadIdx.x == 0) a.loss[0] = mr_total(a.terms);
   for (int nidx = blockIdx.x * 256 + threadIdx.x; nidx < L; nidx += gridDim.x * 256) {
     float s = 0.f;
-#pragma unroll
-    for (int r = 0; r < MR_NRES; ++r) {
-      const int N = a.n[r], half = N / 2;
+    auto one = [&](auto rc, auto nc, auto wc, auto hc) __attribute__((always_inline)) {
+      constexpr int r = decltype(rc)::value, N = decltype(nc)::value, WIN = decltype(wc)::value, HOP = decltype(hc)::value, half = N / 2;
       const int nseg = (a.F[r] + 7) / 8;
-      const float2* fr = (const float2*)a.frames[r] + (long)b * nseg * (7 * a.hop[r] + a.win[r]);
-      float2 g = mr_gather(fr, N, a.win[r], a.hop[r], nseg, nidx + half);                                  // the sample itself
-      if (nidx >= 1 && nidx <= half) { const float2 v = mr_gather(fr, N, a.win[r], a.hop[r], nseg, half - nidx); g.x += v.x; g.y += v.y; }   // left mirror: p = -n
-      const int pr = 2 * (L - 1) - nidx;                                                                    // right mirror: p = 2(L-1) - n
-      if (nidx <= L - 2 && pr < L + half) { const float2 v = mr_gather(fr, N, a.win[r], a.hop[r], nseg, pr + half); g.x += v.x; g.y += v.y; }
+      const float2* fr = (const float2*)a.frames[r] + (long)b * nseg * (7 * HOP + WIN);
+      float2 g = mr_gather<N, WIN, HOP>(fr, nseg, nidx + half);                                                       // the sample itself
+      if (nidx >= 1 && nidx <= half) { const float2 v = mr_gather<N, WIN, HOP>(fr, nseg, half - nidx); g.x += v.x; g.y += v.y; }   // left mirror: p = -n
+      const int pr = 2 * (L - 1) - nidx;                                                                              // right mirror: p = 2(L-1) - n
+      if (nidx <= L - 2 && pr < L + half) { const float2 v = mr_gather<N, WIN, HOP>(fr, nseg, pr + half); g.x += v.x; g.y += v.y; }
       s += a.coef[r][1 + b] * g.x + a.coef[r][0] * g.y;         // the global coefficients of mr_finalize: spectral convergence (per waveform), log magnitude
-    }
+    };
+    using std::integral_constant;                                // the three resolutions, in MR_NFFT / MR_WIN / MR_HOP order (checked on the host)
+    one(integral_constant<int, 0>{}, integral_constant<int, 1024>{}, integral_constant<int, 600>{}, integral_constant<int, 120>{});
+    one(integral_constant<int, 1>{}, integral_constant<int, 2048>{}, integral_constant<int, 1200>{}, integral_constant<int, 240>{});
+    one(integral_constant<int, 2>{}, integral_constant<int, 512>{}, integral_constant<int, 240>{}, integral_constant<int, 50>{});
     a.d_x[(long)b * L + nidx] = s;
   }
 }
@@ -342,6 +350,8 @@ extern "C" int svs_mrstft_loss_fwd_bwd(const float* x, const float* y, int B, in
   const MrWs w = mr_layout(B, L, ws);
   if (!ws || ws_bytes < w.total || !svs_aligned16(ws)) { svs_set_error("svs_mrstft_loss_fwd_bwd: workspace too small (%zu < %zu)", ws_bytes, w.total); return SVS_ERR_WORKSPACE; }
   static_assert(MrCfg<1024>::WIN == 600 && MrCfg<2048>::WIN == 1200 && MrCfg<512>::WIN == 240, "MrCfg::WIN must match MR_WIN");
+  SVS_REQUIRE(MR_NFFT[0] == 1024 && MR_NFFT[1] == 2048 && MR_NFFT[2] == 512 && MR_HOP[0] == 120 && MR_HOP[1] == 240 && MR_HOP[2] == 50 &&
+              MR_WIN[0] == 600 && MR_WIN[1] == 1200 && MR_WIN[2] == 240, "svs_mrstft_loss_fwd_bwd: mr_ola_kernel is compiled for other resolutions");
   int rc;
   MrArgs a[MR_NRES];
   MrFinalArgs f{};
