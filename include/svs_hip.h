@@ -53,7 +53,8 @@ const char* svs_last_error_string(void);
  * layer instead of per-position counts on the tap-skipping layers), CONV_C1_TILED (0: the thread-per-pixel form of the
  * single-channel convolution), BF16_KB (K-tiles per barrier of the bf16 GEMM: 1, 2 or 4), BF16_CFG / BF16_KSPLIT (its tile / K-split),
  * CONV_PF / WGRAD_PF (K-tiles the fp32 conv / weight-gradient GEMMs request ahead: 1 or 2; CONV_PF 3: on every tile shape),
- * BF16_CONV3_WINDOW / BF16_DECONV3_WINDOW (0: conv3 / deconv3 of the bf16 network in the GEMM form),
+ * CONV_GWINDOW (0: conv2 forward on the GEMM kernel instead of the LDS-window kernel; 2: the window kernel whenever the layer is
+ * eligible; >= 16: that many blocks), BF16_CONV3_WINDOW / BF16_DECONV3_WINDOW (0: conv3 / deconv3 of the bf16 network in the GEMM form),
  * BN_INLINE (most partial rows a BatchNorm apply kernel folds itself instead of waiting for a finalise launch; 0: never;
  * default 128), BN_BLOCKS (blocks of the BatchNorm reduce / apply kernels, <= 1024; default 512),
  * or "*" for all; value -1 = planner

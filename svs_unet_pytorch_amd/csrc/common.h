@@ -50,7 +50,7 @@ enum SvsTune {
   SVS_TUNE_CONV_CFG, SVS_TUNE_CONV_KSPLIT, SVS_TUNE_CONV_WINDOW, SVS_TUNE_CONV_SKIP, SVS_TUNE_CONV_KORDER,
   SVS_TUNE_CONV_DIRECT, SVS_TUNE_SKIP_REDUCE, SVS_TUNE_WGRAD_CFG, SVS_TUNE_WGRAD_KSPLIT, SVS_TUNE_WGRAD_SKIP,
   SVS_TUNE_WGRAD_WINDOW, SVS_TUNE_WGRAD_C1_VALU, SVS_TUNE_SIDE_PRIORITY, SVS_TUNE_TRAIN_UNFUSED,
-  SVS_TUNE_TRAIN_ONE_STREAM, SVS_TUNE_CONV_PLAN, SVS_TUNE_MFMA_SPLIT, SVS_TUNE_CONV_BALANCE, SVS_TUNE_CONV_C1_TILED, SVS_TUNE_BF16_KB, SVS_TUNE_BF16_CFG, SVS_TUNE_BF16_KSPLIT, SVS_TUNE_CONV_PF, SVS_TUNE_WGRAD_PF, SVS_TUNE_BN_INLINE, SVS_TUNE_BN_BLOCKS, SVS_TUNE_BF16_CONV3_WINDOW, SVS_TUNE_BF16_DECONV3_WINDOW, SVS_TUNE_COUNT
+  SVS_TUNE_TRAIN_ONE_STREAM, SVS_TUNE_CONV_PLAN, SVS_TUNE_MFMA_SPLIT, SVS_TUNE_CONV_BALANCE, SVS_TUNE_CONV_C1_TILED, SVS_TUNE_BF16_KB, SVS_TUNE_BF16_CFG, SVS_TUNE_BF16_KSPLIT, SVS_TUNE_CONV_PF, SVS_TUNE_WGRAD_PF, SVS_TUNE_BN_INLINE, SVS_TUNE_BN_BLOCKS, SVS_TUNE_BF16_CONV3_WINDOW, SVS_TUNE_BF16_DECONV3_WINDOW, SVS_TUNE_CONV_GWINDOW, SVS_TUNE_COUNT
 };
 long svs_tune(int key);                       // -1 when unset
 static inline bool svs_tune_on(int key) { return svs_tune(key) >= 0; }      // VALUED switches: "has been set" (0 is a value)

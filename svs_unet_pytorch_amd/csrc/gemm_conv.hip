@@ -899,6 +899,109 @@ __global__ __launch_bounds__(256) void splitk_epilogue_stats_kernel(const float*
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// LDS-window form of the GATHER mode for conv2 forward (16 -> 32 channels, stride 2).  On the GEMM kernel every input pixel goes
+// through L2 / LDS 25/4 times with 256 x 32 tiles (PMC: 271 MB per launch at batch 64 for 100 MB of input + output, 78.6 us:
+// the least efficient forward GEMM).  Here a block owns 8 x 16 OUTPUT pixels of one image, stages their 19 x 35 input window
+// once (even / odd columns in separate planes, so that the 16 pixels of a fragment -- two input columns apart -- are adjacent
+// slots; 80-byte slot pitch: conflict-free ds_read_b128), and every tap is 16 MFMAs per wave with the pixel fragments at base +
+// compile-time offset.  Waves (nt, rh): channel tile nt (16 of the 32), output rows 4 rh .. 4 rh + 3.  Weights are the FIRST
+// MFMA operand (D = [channel][pixel]: a lane's four registers are four consecutive channels of one pixel -- one 16-byte store);
+// their fragments come from the gather-packed matrix [n][25][16] in L2, one tap ahead.  K order inside a tap: step s of lane
+// group q is channel 4 q + s, so a fragment is one 16-byte read.  A block walks `tpb` consecutive tiles and leaves ONE row of
+// BatchNorm partials.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_window_kernel(ConvGemmArgs p, int ntiles, int tpb) {
+  constexpr int TH = 8, TW = 16, WR = 2 * TH + 3, WC = 2 * TW + 3, PW = TW + 2, LP = 20;       // LP: floats per slot
+  constexpr int NCH = WR * WC * 4, NST = (NCH + 255) / 256;                                    // 16-byte pieces of the window
+  constexpr unsigned OOB = 0x80000000u;
+  __shared__ __attribute__((aligned(16))) float win[WR * 2 * PW * LP];
+  __shared__ float st[2][2][32];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lrow = lane & 15, q = lane >> 4;
+  const int nt = wave >> 1, rh = wave & 1;
+  const int tiles_w = (p.Wo + TW - 1) / TW, tiles_h = (p.Ho + TH - 1) / TH;
+  const int n = nt * 16 + 4 * q;                                     // this lane's four output channels
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, OOB, 0x00020000);
+  const unsigned w_voff = (unsigned)(((nt * 16 + lrow) * 25 * 16 + q * 4) * 4);                // row n = nt*16 + lrow of the weight matrix
+  f32x4 b4 = {0.f, 0.f, 0.f, 0.f}, sc4 = b4, sh4 = b4;
+  if (p.bias) b4 = *(const f32x4*)(p.bias + n);
+  if (p.scale) { sc4 = *(const f32x4*)(p.scale + n); sh4 = *(const f32x4*)(p.shift + n); }
+  const float* const pbase = &win[((16 * rh) * PW + lrow) * LP + q * 4];                       // window row 8 rh (+ 2 i + kh), plane 0, slot lrow
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+  const int tile_lo = blockIdx.x * tpb, tile_hi = tile_lo + tpb < ntiles ? tile_lo + tpb : ntiles;
+  for (int tile = tile_lo; tile < tile_hi; ++tile) {
+    const int ow0 = (tile % tiles_w) * TW, oh0 = ((tile / tiles_w) % tiles_h) * TH;
+    const long b = tile / (tiles_w * tiles_h);
+    // (the window of the NEXT tile in registers during this tile's MFMAs, as the bf16 window kernels have it, measured slower here:
+    // 76.8 against 72.8 us at batch 64 -- 44 more registers; the second resident block covers the load latency)
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + b * p.H * p.W * p.ldx), 0, OOB, 0x00020000);
+    f32x4 stage[NST];
+#pragma unroll
+    for (int k = 0; k < NST; ++k) {
+      const int e = t + k * 256, c4 = e & 3, px = e >> 2;
+      const int wr = px / WC, wc = px - wr * WC;
+      const int ih = 2 * oh0 - 2 + wr, iw = 2 * ow0 - 2 + wc;
+      const bool ok = e < NCH && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+      const unsigned vo = ok ? (unsigned)(((ih * p.W + iw) * (int)p.ldx + c4 * 4) * 4) : OOB;
+      stage[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)vo, 0, 0));
+    }
+    __syncthreads();                                                 // the previous tile's readers are done
+#pragma unroll
+    for (int k = 0; k < NST; ++k) {
+      const int e = t + k * 256, c4 = e & 3, px = e >> 2;
+      const int wr = px / WC, wc = px - wr * WC;
+      if (e < NCH) *(f32x4*)(&win[((wr * 2 + (wc & 1)) * PW + (wc >> 1)) * LP + c4 * 4]) = stage[k];
+    }
+    __syncthreads();
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 fw[2];
+    fw[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (int)w_voff, 0, 0));
+    svs_static_for<25>([&](auto tc) {
+      constexpr int tap = decltype(tc)::value, kh = tap / 5, kw = tap % 5;
+      if constexpr (tap + 1 < 25) fw[(tap + 1) & 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (int)w_voff, (tap + 1) * 16 * 4, 0));
+      f32x4 fp[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fp[i] = *(const f32x4*)(pbase + (((2 * i + kh) * 2 + (kw & 1)) * PW + (kw >> 1)) * LP);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[tap & 1][k], fp[i][k], acc[i], 0, 0, 0);
+    });
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int oh = oh0 + 4 * rh + i, ow = ow0 + lrow;
+      if (oh >= p.Ho || ow >= p.Wo) continue;
+      f32x4 v = acc[i];
+      if (p.bias) v += b4;
+      if (p.scale) {
+        v = v * sc4 + sh4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : v[k] * p.slope;
+      }
+      *(f32x4*)(p.y + ((b * p.Ho + oh) * p.Wo + ow) * p.ldy + n) = v;
+      s0 += v;
+      s1 += v * v;
+    }
+  }
+  if (p.stats) {                                 // this block's row of BatchNorm partials [2][32]: over the 16 pixels of a row group, then the two row halves
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) { s0[k] += __shfl_xor(s0[k], o, 64); s1[k] += __shfl_xor(s1[k], o, 64); }
+    if (lrow == 0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { st[0][rh][n + k] = s0[k]; st[1][rh][n + k] = s1[k]; }
+    }
+    __syncthreads();
+    if (t < 64) {
+      const int which = t >> 5, c = t & 31;
+      p.stats[(long)blockIdx.x * 64 + which * 32 + c] = st[which][0][c] + st[which][1][c];
+    }
+  }
+}
+
 // ---- host side ---------------------------------------------------------------------------------
 struct ConvPlan { int cfg; int BM, BN; int ksplit; long mtiles; int grid_y; int pf; };
 
@@ -1273,6 +1376,24 @@ int svs_conv_gemm_run(int mode, const float* x, long ldx, int B, int H, int W, i
   }
   if (svs_tune_on(SVS_TUNE_CONV_DIRECT)) { const int f = (int)svs_tune(SVS_TUNE_CONV_DIRECT); if (f == 0 || (N <= 32 && Mmax >= 16384)) direct = f; }  // sweeps
   const bool want_stats = stats && stats_nblk && !scale && !accumulate;
+  // conv2 forward: LDS-window form of the GATHER mode (SVS_CONV_GWINDOW=0: the GEMM kernel)
+  if (mode == MODE_GATHER && C == 16 && N == 32 && !accumulate && ldy % 4 == 0 && svs_aligned16(y) && svs_tune(SVS_TUNE_CONV_GWINDOW) != 0 &&
+      ((long)H * W * ldx) * 4 < (1L << 31)) {
+    const long gtiles = (long)B * ((Ho + 7) / 8) * ((Wo + 15) / 16);
+    const bool forced = svs_tune(SVS_TUNE_CONV_GWINDOW) == 2;          // tests: whenever the layer is eligible
+    if ((forced || (Ho >= 8 && Wo >= 16 && gtiles >= 256)) && gtiles < (1L << 30)) {
+      const long tblocks = svs_tune(SVS_TUNE_CONV_GWINDOW) >= 16 ? svs_tune(SVS_TUNE_CONV_GWINDOW) : 512;     // (>= 16: sweeps)
+      int tpb = (int)(gtiles / tblocks);         // one round of two resident blocks per CU; >= 1 tile per block
+      if (tpb < 1) tpb = 1;
+      if (tpb > 8) tpb = 8;
+      const long gblocks = (gtiles + tpb - 1) / tpb;
+      a.ksplit = 1; a.slab = nullptr;
+      if (want_stats && gblocks * 2 * N <= stats_cap) { a.stats = stats; *stats_nblk = (int)gblocks; }
+      hipLaunchKernelGGL(gather_window_kernel, dim3((unsigned)gblocks), dim3(256), 0, stream, a, (int)gtiles, tpb);
+      SVS_CHECK_LAUNCH("gather_window");
+      return SVS_OK;
+    }
+  }
   if (window) {
     a.ksplit = 1; a.slab = nullptr;
     dim3 grid((unsigned)((long)B * ((H + 7) / 8) * ((W + 15) / 16)));
@@ -1379,6 +1500,11 @@ int svs_conv_gemm_describe(int mode, int B, int H, int W, int C, int Ho, int Wo,
   if (Mmax >= 16384 && ((long)B * H * W * ldx + 4L * (W + 2) * ldx) * 4 < (1L << 31)) {
     if (N == 16) direct = 1;
     else if (N == 32 && mode == MODE_PARITY && C >= 128) direct = 1;
+  }
+  if (mode == MODE_GATHER && C == 16 && N == 32 && svs_tune(SVS_TUNE_CONV_GWINDOW) != 0 && Ho >= 8 && Wo >= 16 &&
+      (long)B * ((Ho + 7) / 8) * ((Wo + 15) / 16) >= 256) {
+    snprintf(buf, n, "gather_window_kernel");
+    return 1;
   }
   if (use_parity_window(mode, B, H, W, C, N, ldx)) {
     const bool halves = N == 32 && parity_window_halves((long)B * ((H + 7) / 8) * ((W + 15) / 16));

@@ -37,7 +37,7 @@ extern "C" const char* svs_last_error_string(void) { return g_err; }
 // ---------------------------------------------------------------------------------------------
 static const char* const TUNE_NAMES[SVS_TUNE_COUNT] = {
     "CONV_CFG", "CONV_KSPLIT", "CONV_WINDOW", "CONV_SKIP", "CONV_KORDER", "CONV_DIRECT", "SKIP_REDUCE", "WGRAD_CFG",
-    "WGRAD_KSPLIT", "WGRAD_SKIP", "WGRAD_WINDOW", "WGRAD_C1_VALU", "SIDE_PRIORITY", "TRAIN_UNFUSED", "TRAIN_ONE_STREAM", "CONV_PLAN", "MFMA_SPLIT", "CONV_BALANCE", "CONV_C1_TILED", "BF16_KB", "BF16_CFG", "BF16_KSPLIT", "CONV_PF", "WGRAD_PF", "BN_INLINE", "BN_BLOCKS", "BF16_CONV3_WINDOW", "BF16_DECONV3_WINDOW"};
+    "WGRAD_KSPLIT", "WGRAD_SKIP", "WGRAD_WINDOW", "WGRAD_C1_VALU", "SIDE_PRIORITY", "TRAIN_UNFUSED", "TRAIN_ONE_STREAM", "CONV_PLAN", "MFMA_SPLIT", "CONV_BALANCE", "CONV_C1_TILED", "BF16_KB", "BF16_CFG", "BF16_KSPLIT", "CONV_PF", "WGRAD_PF", "BN_INLINE", "BN_BLOCKS", "BF16_CONV3_WINDOW", "BF16_DECONV3_WINDOW", "CONV_GWINDOW"};
 static std::atomic<long> g_tune[SVS_TUNE_COUNT];      // written by svs_tuning_set while compute threads read: relaxed atomics
 static std::once_flag g_tune_once;
 static void tune_load_env() {

@@ -132,6 +132,40 @@ def test_enc_block_fwd(B, H, W, C, N, rows, report, tune):
     assert report(f"enc_fwd acc B{B} {H}x{W} C{C} N{N}", e, 2e-5)
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 64, 32), (1, 33, 9), (3, 70, 50), (40, 64, 32)])
+def test_conv2_gather_window(B, H, W, report, tune):
+    """conv2 forward in the LDS-window form (gather_window_kernel: 16 -> 32 channels), forced on small and odd shapes; raw output with
+    bias into a strided view, the BatchNorm partial rows it leaves (through svs_unet-independent ops: their sum must equal the
+    channel sums of the output), and the eval epilogue."""
+    C, N = 16, 32
+    tune("CONV_GWINDOW", 2)
+    buf = ctypes.create_string_buffer(128)
+    x = rnd((B, C, H, W), 10)
+    w = rnd((N, C, 5, 5), 11, -0.1, 0.1)
+    b = rnd((N,), 12)
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    want = F.conv2d(x.double(), w.double(), b.double(), stride=2, padding=2)
+    xd = torch.full((B, H, W, C + 4), 5.0, device=DEV)
+    xd[..., :C] = nhwc(x).to(DEV)
+    wp = pack_gather(w)
+    bd = b.to(DEV)
+    y = torch.full((B, Ho, Wo, 2 * N), 7.0, device=DEV)
+    ws = ws_tensor(L().svs_enc_block_workspace_bytes(B, H, W, C, N))
+    _lib.check(L().svs_enc_block_fwd(xd.data_ptr(), C + 4, B, H, W, C, wp.data_ptr(), bd.data_ptr(), None, None, 0.0,
+                                     y.data_ptr() + 4 * N, 2 * N, N, 0, ws.data_ptr(), ws.numel(), S()))
+    torch.cuda.synchronize()
+    assert torch.all(y[..., :N] == 7.0), "wrote outside its channel slice"
+    assert report(f"conv2 window raw B{B} {H}x{W}", relerr(nchw(y[..., N:]), want), 2e-5)
+    sc, sh = rnd((N,), 13, 0.5, 1.5), rnd((N,), 14)
+    want2 = F.leaky_relu(F.conv2d(x.double(), w.double(), None, stride=2, padding=2) * sc.double()[None, :, None, None]
+                         + sh.double()[None, :, None, None], 0.2)
+    y2 = torch.empty((B, Ho, Wo, N), device=DEV)
+    scd, shd = sc.to(DEV), sh.to(DEV)
+    _lib.check(L().svs_enc_block_fwd(xd.data_ptr(), C + 4, B, H, W, C, wp.data_ptr(), None, scd.data_ptr(), shd.data_ptr(), 0.2,
+                                     y2.data_ptr(), N, N, 0, ws.data_ptr(), ws.numel(), S()))
+    assert report(f"conv2 window epi B{B} {H}x{W}", relerr(nchw(y2), want2), 2e-5)
+
+
 @pytest.mark.parametrize("kind,B,H,W,C,N", [("conv", 4, 32, 16, 128, 256), ("conv", 2, 64, 32, 32, 64), ("deconv", 4, 8, 4, 512, 128), ("wgrad", 8, 16, 8, 128, 256)])
 def test_mfma_split_mode_accuracy(kind, B, H, W, C, N, report, tune):
     """The optional product mode of the GEMM kernels (csrc/mfma_split.h: fp32 operands split exactly into three bf16 limbs, six
